@@ -1,0 +1,117 @@
+/* r3m_hip.h — C ABI of libr3m_hip.so, the MI355X (gfx950) hot path of R3M representation pre-training.
+ *
+ * The reference (facebookresearch/r3m, mounted at /root/reference) has no FFI of its own: everything below replaces
+ * work the reference reaches through PyTorch / torchvision / torch.optim. Each entry point cites the reference call
+ * site(s) whose arithmetic it takes over.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked host;
+ *   - no allocation, no ownership transfer, no hidden synchronisation: work is enqueued on `stream` and returns;
+ *   - outputs and workspaces are pre-allocated by the caller (`*_workspace_bytes` / `*_arena_bytes` queries);
+ *   - return 0 on success, non-zero on failure with a thread-local message in r3m_last_error();
+ *   - activations are NHWC fp32, conv weights OHWI fp32 (= torch OIHW tensors with channels_last strides);
+ *   - re-entrant; a `r3m_resnet_t` handle must not be used from two threads at once.
+ */
+#ifndef R3M_HIP_H
+#define R3M_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* r3m_stream_t;  /* hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) */
+typedef struct r3m_resnet* r3m_resnet_t;
+
+int r3m_abi_version(void);
+const char* r3m_last_error(void);
+
+/* ---------------- encoder engine -----------------------------------------------------------------------------
+ * Replaces torchvision.models.resnet{18,34,50}(pretrained=False) with fc=Identity as built by R3M.__init__
+ * (r3m/models/models_r3m.py:44-52,62-63) and run by R3M.forward (models_r3m.py:84-100: x/255 -> Normalize -> convnet);
+ * backward replaces autograd through that graph (r3m/trainer.py:157).                                            */
+r3m_resnet_t r3m_resnet_create(int size /*18|34|50*/, int frames);
+void r3m_resnet_destroy(r3m_resnet_t h);
+int r3m_resnet_out_dim(r3m_resnet_t h);                 /* 512 | 512 | 2048 (models_r3m.py:45,48,51) */
+long long r3m_resnet_num_params(r3m_resnet_t h);        /* floats in the flat parameter / gradient buffers */
+long long r3m_resnet_num_buffers(r3m_resnet_t h);       /* floats in the flat running-statistics buffer */
+long long r3m_resnet_arena_bytes(r3m_resnet_t h);       /* activation + scratch arena for `frames` */
+int r3m_resnet_num_tensors(r3m_resnet_t h);
+/* i-th tensor in torchvision state-dict order. kind: 0 conv weight (shape O,I,kh,kw; stored OHWI), 1 bn weight,
+ * 2 bn bias (offsets into params), 3 running_mean, 4 running_var (offsets into buffers). */
+int r3m_resnet_tensor_info(r3m_resnet_t h, int i, char* name, int name_cap, int* kind, long long* offset, int* ndim,
+                           int* shape4);
+/* backward stage s (0: avgpool+layer4, 1: layer3, 2: layer2, 3: layer1+stem) finishes params [offset, offset+count) */
+int r3m_resnet_stage_range(r3m_resnet_t h, int stage, long long* offset, long long* count);
+/* x: [frames,3,224,224] fp32 NCHW in 0..255 (models_r3m.py:96: "Input must be [0, 255]"); h_out: [frames, out_dim].
+ * training=1: batch statistics + running-stat update (momentum 0.1, eps 1e-5); 0: running statistics. */
+int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, float* buffers, void* arena, float* h_out,
+                       int training, r3m_stream_t stream);
+/* dh: [frames, out_dim]. Runs stages [stage_begin, stage_end) in order; stage 0 must come first after a forward.
+ * accumulate=0 overwrites grads, 1 adds to them. */
+int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
+                        int stage_end, int accumulate, r3m_stream_t stream);
+
+/* ---------------- single operators (parity-tested one by one) -------------------------------------------------
+ * conv2d fwd / dgrad / wgrad: ATen conv2d + autograd under torchvision ResNet.forward (call site models_r3m.py:99). */
+int r3m_conv2d_stats_rows(int N, int Hi, int Wi, int Co, int k, int stride, int pad);
+/* stats (optional): [stats_rows][2][Co] per-row-block sum / sum of squares of y (BatchNorm statistics partials) */
+int r3m_conv2d_fwd(const float* x, const float* w_ohwi, float* y, float* stats, int N, int Hi, int Wi, int Ci, int Co, int k,
+                   int stride, int pad, r3m_stream_t stream);
+size_t r3m_conv2d_dgrad_workspace_bytes(int Ci, int Co, int k);
+int r3m_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, void* workspace, size_t workspace_bytes, int N, int Hi,
+                     int Wi, int Ci, int Co, int k, int stride, int pad, r3m_stream_t stream);
+size_t r3m_conv2d_wgrad_workspace_bytes(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
+int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int N, int Hi,
+                     int Wi, int Ci, int Co, int k, int stride, int pad, int accumulate, r3m_stream_t stream);
+/* stem input transform: x/255 -> Normalize(mean,std) -> 7x7/2 p3 patches as rows of 160 floats (models_r3m.py:61,97-98) */
+int r3m_stem_im2col(const float* x_nchw, float* col, int frames, r3m_stream_t stream);
+
+/* BatchNorm2d(eps, momentum) train/eval + ReLU + residual add (torchvision BasicBlock/Bottleneck).
+ * coef: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale. */
+size_t r3m_bn_workspace_bytes(long long rows, int C);
+int r3m_bn_train_coeffs(const float* stats, int stats_rows, long long count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* coef, void* workspace,
+                        size_t workspace_bytes, int C, r3m_stream_t stream);
+int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* coef, int C, r3m_stream_t stream);
+/* z = [relu](scale*y + shift [+ r] [+ scale2*y2 + shift2]) ; pass r for the identity branch, or y2+coef2 for a
+ * downsample branch (then r must be NULL). */
+int r3m_bn_act_fwd(const float* y, const float* coef, const float* r, const float* y2, const float* coef2, float* z,
+                   long long rows, int C, int relu, r3m_stream_t stream);
+/* g = dz * [mask], mask = (zmask > 0) if zmask else (scale*y+shift > 0); dgamma = sum g*yhat, dbeta = sum g,
+ * dy = scale*(g - mean(g) - yhat*mean(g*yhat)) (batch stats) or scale*g (use_batch_stats=0). */
+int r3m_bn_bwd(const float* dz, const float* zmask, const float* y, const float* coef, float* dgamma, float* dbeta, float* dy,
+               void* workspace, size_t workspace_bytes, long long rows, int C, int use_batch_stats, int accumulate,
+               r3m_stream_t stream);
+/* MaxPool2d(3,2,1) and AdaptiveAvgPool2d(1)+flatten, NHWC */
+int r3m_maxpool_fwd(const float* z, float* p, unsigned char* argmax, int N, int Hi, int Wi, int C, r3m_stream_t stream);
+int r3m_maxpool_bwd(const float* dp, const unsigned char* argmax, float* dz, int N, int Hi, int Wi, int C, r3m_stream_t stream);
+int r3m_avgpool_fwd(const float* x, float* h, int N, int HW, int C, r3m_stream_t stream);
+int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream_t stream);
+
+/* nn.Linear (+ReLU) of LanguageReward.pred (r3m/models/models_language.py:43-51): y[M,N] = x[M,K] w[N,K]^T + b */
+int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu,
+                   r3m_stream_t stream);
+
+/* ---------------- objective (r3m/trainer.py:39-152, R3M.sim models_r3m.py:102-107) ----------------------------
+ * alle [B,5,D] (e0, eg, es0, es1, es2 per clip); perm/iperm [6][B] int32: the reference's torch.randperm draws in
+ * order (es0-perm, es2-perm) x 3 (trainer.py:136-137) and their inverses. Writes d(full_loss)/d(alle) to dalle
+ * (may be NULL: metrics only). workspace: r3m_loss_workspace_bytes(B).  */
+size_t r3m_loss_workspace_bytes(int B);
+int r3m_loss_tcn_lp(const float* alle, const int* perm, const int* iperm, float* dalle, void* workspace, size_t workspace_bytes,
+                    int B, int D, int l2dist, float l2weight, float l1weight, float tcnweight, r3m_stream_t stream);
+/* scores [15][B] of the 15 get_reward calls in reference order (trainer.py:72-92); mask [B] (trainer.py:107-109);
+ * dscore [15][B] = d(full_loss)/d(score). Same workspace as r3m_loss_tcn_lp. */
+int r3m_loss_lang_infonce(const float* scores, const float* mask, float* dscore, void* workspace, size_t workspace_bytes, int B,
+                          float langweight, r3m_stream_t stream);
+/* metrics[16]: 0 l2loss 1 l1loss 2 l0loss 3 tcnloss 4 aligned 5 rewloss 6-8 rewacc1-3 9 full_loss (trainer.py:55-57,111-117,147-152) */
+int r3m_loss_finalize(void* workspace, size_t workspace_bytes, int B, int have_lang, float* metrics, float l2weight,
+                      float l1weight, float tcnweight, float langweight, r3m_stream_t stream);
+
+/* ---------------- optimizer: torch.optim.Adam(params, lr) defaults (models_r3m.py:76; trainer.py:156-158) -------
+ * one pass over the flat buffers; step counts from 1; grad_scale multiplies g on the fly (1/world_size for SUM all-reduce) */
+int r3m_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1,
+                  double beta2, double eps, long long step, float grad_scale, r3m_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,441 @@
+// r3m_amd — BatchNorm2d (train / eval) forward + backward fused with ReLU and the residual add, MaxPool 3x3/2 and the
+// global average pool, for NHWC fp32 activations on gfx950. All of these are HBM-bound passes: float4 (16 B / lane)
+// coalesced streams, per-channel coefficients re-read from L1/L2, fixed-order reductions (bit-reproducible run to run).
+//
+// Reference semantics: torchvision ResNet BatchNorm2d(eps=1e-5, momentum=0.1) + ReLU + MaxPool2d(3,2,1) +
+// AdaptiveAvgPool2d(1) as instantiated at /root/reference/r3m/models/models_r3m.py:44-52,62-63.
+//   train: normalise with the biased batch variance, update running_var with the unbiased one;
+//   statistics: the conv epilogue (conv.hip EPI_STATS) leaves fp32 per-row-block sum / sum-of-squares, which are
+//   combined here in fp64, so E[y^2] - mean^2 is evaluated without fp32 cancellation.
+#include "common.h"
+
+namespace r3m {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// partials [rows][2][C] (fp32)  ->  acc [S][2][C] (fp64), S = gridDim.y slices, fixed order inside a slice
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __restrict__ partials, int rows, int C,
+                                                               double* __restrict__ acc) {
+  __shared__ double red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    for (int r = blockIdx.y * 4 + ty; r < rows; r += 4 * gridDim.y) {
+      s += (double)partials[((long long)r * 2 + 0) * C + c];
+      ss += (double)partials[((long long)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][ty][tx] = s;
+  red[1][ty][tx] = ss;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    s = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    ss = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    acc[((long long)blockIdx.y * 2 + 0) * C + c] = s;
+    acc[((long long)blockIdx.y * 2 + 1) * C + c] = ss;
+  }
+}
+
+static inline int reduce_slices(int rows) {
+  int s = (rows + 15) / 16;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// acc must hold 64*2*C doubles; the slice count is a pure function of the partial-row count (reduce_slices), so
+// the finalize launchers below take the same `stat_rows` and recompute it.
+int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc, hipStream_t s) {
+  const int S = reduce_slices(rows);
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(ceil_div(C, 64), S), dim3(256), 0, s, partials, rows, C, acc);
+  return check_launch("bn_stats_reduce");
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
+                                                           double unbias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum, float eps,
+                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                           float* __restrict__ scale_o, float* __restrict__ shift_o, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int i = 0; i < S; ++i) {
+    s += acc[((long long)i * 2 + 0) * C + c];
+    ss += acc[((long long)i * 2 + 1) * C + c];
+  }
+  const double mean = s * inv_count;
+  double var = ss * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean;
+  const float varf = (float)var;
+  const float invstd = 1.0f / sqrtf(varf + eps);
+  const float sc = gamma[c] * invstd;
+  mean_o[c] = meanf;
+  invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = fmaf(-meanf, sc, beta[c]);
+  if (running_mean) {
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  }
+}
+
+// `stat_rows` = number of partial rows that were reduced (fixes the slice count), `count` = elements per channel.
+int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                            float* invstd, float* scale, float* shift, int C, hipStream_t s) {
+  const double inv_count = 1.0 / (double)count;
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, acc, reduce_slices(stat_rows), inv_count,
+                     unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+  return check_launch("bn_finalize");
+}
+
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ rm, const float* __restrict__ rv,
+                                                              float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                              float* __restrict__ scale_o, float* __restrict__ shift_o, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  mean_o[c] = rm[c];
+  invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = fmaf(-rm[c], sc, beta[c]);
+}
+
+int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, gamma, beta, running_mean,
+                     running_var, eps, mean, invstd, scale, shift, C);
+  return check_launch("bn_eval_coeffs");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Z = [relu]( scale*Y + shift  [+ R]  [+ scale2*Y2 + shift2] )      (one read per operand, one write)
+//   R      : identity branch (already activated block input)
+//   Y2,... : downsample branch raw conv output with its own BatchNorm coefficients
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>  // 0: plain, 1: + R, 2: + affine(Y2)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ R,
+                                                          const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                          float* __restrict__ Z, long long n4, int c4mask, int relu) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = ((int)(i & c4mask)) * 4;
+  const f32x4 y = ld4(Y + i * 4);
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
+  f32x4 z;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z[e] = fmaf(y[e], sc[e], sh[e]);
+  if (MODE == 1) {
+    const f32x4 r = ld4(R + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] += r[e];
+  } else if (MODE == 2) {
+    const f32x4 y2 = ld4(R + i * 4);
+    const f32x4 sc2 = ld4(scale2 + c), sh2 = ld4(shift2 + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] += fmaf(y2[e], sc2[e], sh2[e]);
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = fmaxf(z[e], 0.f);
+  }
+  st4(Z + i * 4, z);
+}
+
+static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
+                      const float* shift2, float* Z, long long rows, int C, int relu, hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_act_fwd: C=%d must be a power of two >= 4", C);
+  const long long n4 = rows * C / 4;
+  const int grid = ceil_div(n4, 256);
+  const int c4mask = C / 4 - 1;
+  if (R && scale2)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+  else if (R)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+  else
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+  return check_launch("bn_act_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm backward, pass 1:  per-channel  sum(g)  and  sum(g * yhat),  g = dZ * [z > 0],  yhat = (y-mean)*invstd.
+// The ReLU mask is either read from the saved activation (Zmask: residual blocks, where z also depends on the
+// identity branch) or recomputed from y with the very same fmaf the forward used (no extra read).
+// Work split: a block owns RB consecutive rows x up to 1024 channels; each thread keeps 4 channels in registers.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
+                                                             const float* __restrict__ Y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ partials,
+                                                             long long rows, int C, int cpb4, int rows_per_block) {
+  __shared__ f32x4 red[2][256];
+  const int tcol = threadIdx.x % cpb4, trow = threadIdx.x / cpb4;
+  const int rpp = 256 / cpb4;
+  const int c = (blockIdx.y * cpb4 + tcol) * 4;
+  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = r_begin + trow; r < r_end; r += rpp) {
+    const long long off = r * C + c;
+    const f32x4 y = ld4(Y + off);
+    const f32x4 dz = ld4(dZ + off);
+    f32x4 g;
+    if (Zmask) {
+      const f32x4 z = ld4(Zmask + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += g[e];
+      s2[e] = fmaf(g[e], (y[e] - mu[e]) * is[e], s2[e]);
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (trow == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s1 += red[0][k * cpb4 + tcol];
+      s2 += red[1][k * cpb4 + tcol];
+    }
+    st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c, s1);
+    st4(partials + ((long long)blockIdx.x * 2 + 1) * C + c, s2);
+  }
+}
+
+static inline void bwd_geometry(long long rows, int C, int* cpb4, int* rpb, int* nblk) {
+  int c4 = C / 4;
+  *cpb4 = c4 < 256 ? c4 : 256;
+  const int rpp = 256 / *cpb4;
+  *rpb = 32 * rpp;
+  *nblk = ceil_div(rows, *rpb);
+}
+
+int bn_bwd_partial_rows(long long rows, int C) {
+  int cpb4, rpb, nblk;
+  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+  return nblk;
+}
+
+int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float* partials, long long rows, int C, hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce: C=%d must be a power of two >= 4", C);
+  int cpb4, rpb, nblk;
+  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s, dZ, Zmask, Y, scale, shift,
+                     mean, invstd, partials, rows, C, cpb4, rpb);
+  return check_launch("bn_bwd_reduce");
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
+                                                               int use_batch_stats, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ c1,
+                                                               float* __restrict__ c2, int accumulate, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgy = 0.0;
+  for (int i = 0; i < S; ++i) {
+    sg += acc[((long long)i * 2 + 0) * C + c];
+    sgy += acc[((long long)i * 2 + 1) * C + c];
+  }
+  const float db = (float)sg, dg = (float)sgy;
+  dbeta[c] = accumulate ? dbeta[c] + db : db;
+  dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  c1[c] = use_batch_stats ? (float)(sg * inv_count) : 0.f;
+  c2[c] = use_batch_stats ? (float)(sgy * inv_count) : 0.f;
+}
+
+int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
+                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, acc, reduce_slices(stat_rows),
+                     1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C);
+  return check_launch("bn_bwd_finalize");
+}
+
+// pass 2:  dY = scale * (g - c1 - yhat * c2)       (c1 = mean(g), c2 = mean(g*yhat); both 0 in eval mode)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
+                                                            const float* __restrict__ Y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                            const float* __restrict__ c2, float* __restrict__ dY,
+                                                            long long n4, int c4mask) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = ((int)(i & c4mask)) * 4;
+  const f32x4 y = ld4(Y + i * 4);
+  const f32x4 dz = ld4(dZ + i * 4);
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
+  const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
+  f32x4 g;
+  if (Zmask) {
+    const f32x4 z = ld4(Zmask + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
+  }
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float yh = (y[e] - mu[e]) * is[e];
+    o[e] = sc[e] * (g[e] - k1[e] - yh * k2[e]);
+  }
+  st4(dY + i * 4, o);
+}
+
+int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
+                        long long rows, int C, hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_apply: C=%d must be a power of two >= 4", C);
+  const long long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, dZ, Zmask, Y, scale, shift, mean,
+                     invstd, c1, c2, dY, n4, C / 4 - 1);
+  return check_launch("bn_bwd_apply");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1), NHWC. Forward keeps the window-local argmax (0..8, first maximum in
+// row-major scan order, like ATen) in one byte per output element; backward is a gather over the <= 4 windows that
+// contain an input pixel, so it needs neither atomics nor a zero-fill pass.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ Z, float* __restrict__ P,
+                                                           unsigned char* __restrict__ amax, long long total, int Hi, int Wi,
+                                                           int Ho, int Wo, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  long long t = idx / C4;
+  const int px = (int)(t % Wo); t /= Wo;
+  const int py = (int)(t % Ho);
+  const long long n = t / Ho;
+  f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  bool first = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int y = py * 2 - 1 + i;
+    if ((unsigned)y >= (unsigned)Hi) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = px * 2 - 1 + j;
+      if ((unsigned)x >= (unsigned)Wi) continue;
+      const f32x4 v = ld4(Z + (((n * Hi + y) * Wi + x) * C4 + c4) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = i * 3 + j; }
+      first = false;
+    }
+  }
+  st4(P + idx * 4, best);
+  *reinterpret_cast<uchar4*>(amax + idx * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+}
+
+int launch_maxpool_fwd(const float* Z, float* P, unsigned char* amax, int N, int Hi, int Wi, int C, hipStream_t s) {
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, Z, P, amax, total, Hi, Wi, Ho, Wo, C / 4);
+  return check_launch("maxpool_fwd");
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                           float* __restrict__ dZ, long long total, int Hi, int Wi, int Ho,
+                                                           int Wo, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  long long t = idx / C4;
+  const int x = (int)(t % Wi); t /= Wi;
+  const int y = (int)(t % Hi);
+  const long long n = t / Hi;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  // windows py with 2*py-1 <= y <= 2*py+1
+  const int py0 = y >> 1, py1 = (y + 1) >> 1;
+  const int px0 = x >> 1, px1 = (x + 1) >> 1;
+  for (int py = py0; py <= py1; ++py) {
+    if (py >= Ho) continue;
+    const int i = y - (py * 2 - 1);
+    for (int px = px0; px <= px1; ++px) {
+      if (px >= Wo) continue;
+      const int j = x - (px * 2 - 1);
+      const int code = i * 3 + j;
+      const long long o = (((n * Ho + py) * Wo + px) * C4 + c4) * 4;
+      const uchar4 a = *reinterpret_cast<const uchar4*>(amax + o);
+      const f32x4 d = ld4(dP + o);
+      if (a.x == code) g[0] += d[0];
+      if (a.y == code) g[1] += d[1];
+      if (a.z == code) g[2] += d[2];
+      if (a.w == code) g[3] += d[3];
+    }
+  }
+  st4(dZ + idx * 4, g);
+}
+
+int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, int N, int Hi, int Wi, int C, hipStream_t s) {
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Hi * Wi * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dP, amax, dZ, total, Hi, Wi, Ho, Wo, C / 4);
+  return check_launch("maxpool_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(1) + flatten: [N, HW, C] -> [N, C]  and its backward (broadcast of dH / HW)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ X, float* __restrict__ H, long long total,
+                                                           int HW, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  const long long n = idx / C4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < HW; ++p) s += ld4(X + ((n * HW + p) * C4 + c4) * 4);
+  const float d = (float)HW;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = s[e] / d;
+  st4(H + idx * 4, s);
+}
+
+int launch_avgpool_fwd(const float* X, float* H, int N, int HW, int C, hipStream_t s) {
+  const long long total = (long long)N * (C / 4);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, X, H, total, HW, C / 4);
+  return check_launch("avgpool_fwd");
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dH, float* __restrict__ dX, long long total,
+                                                           int HW, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  const long long n = idx / ((long long)HW * C4);
+  f32x4 g = ld4(dH + (n * C4 + c4) * 4);
+  const float d = (float)HW;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) g[e] = g[e] / d;
+  st4(dX + idx * 4, g);
+}
+
+int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStream_t s) {
+  const long long total = (long long)N * HW * (C / 4);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dH, dX, total, HW, C / 4);
+  return check_launch("avgpool_bwd");
+}
+
+}  // namespace r3m

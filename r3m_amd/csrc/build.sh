@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libr3m_hip.so for gfx950 (MI355X). hipcc cross-compiles without a GPU. Usage: build.sh [extra hipcc flags]
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/../../build/obj"
+OBJ="$HERE/../../build/obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
+pids=()
+for f in conv bn loss adam lang engine capi; do
+  [ -f "$HERE/$f.hip" ] || continue
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/r3m_hip.h" -nt "$OBJ/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+objs=()
+for f in conv bn loss adam lang engine capi; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libr3m_hip.so" "${objs[@]}"
+echo "built $OUT/libr3m_hip.so"

@@ -1,0 +1,202 @@
+// r3m_amd — extern "C" surface of libr3m_hip.so (declared in include/r3m_hip.h).
+#include "common.h"
+#include "../../include/r3m_hip.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace r3m {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// engine.hip
+struct Plan;
+Plan* plan_create(int size, int F);
+int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
+                 hipStream_t s);
+int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
+                  int accumulate, int* gd_io, hipStream_t s);
+int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
+                        int Co, int k, int stride, int pad, int flags, hipStream_t s);
+int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, int N, int Hi, int Wi,
+                      int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
+int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
+                      int stride, int pad, int accumulate, hipStream_t s);
+size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
+// accessors implemented in engine.hip
+int plan_out_dim(Plan*);
+long long plan_num_params(Plan*);
+long long plan_num_buffers(Plan*);
+long long plan_arena_floats(Plan*);
+int plan_num_tensors(Plan*);
+int plan_tensor_info(Plan*, int i, char* name, int cap, int* kind, long long* offset, int* ndim, int* shape4);
+int plan_stage_range(Plan*, int stage, long long* off, long long* count);
+void plan_destroy(Plan*);
+int* plan_gd(Plan*);
+// loss.hip / adam.hip
+size_t loss_workspace_floats(int B);
+int launch_tcn_lp_loss(const float* alle, const int* perm, const int* iperm, float* dalle, float* ws, int B, int D, int l2dist,
+                       float l2w, float l1w, float tcnw, hipStream_t s);
+int launch_lang_infonce(const float* scores, const float* mask, float* dscore, float* ws, int B, float langw, hipStream_t s);
+int launch_loss_finalize(float* ws, int B, int have_lang, float* metrics, float l2w, float l1w, float tcnw, float langw,
+                         hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                long long step, float grad_scale, hipStream_t s);
+
+}  // namespace r3m
+
+using namespace r3m;
+
+#define S(x) reinterpret_cast<hipStream_t>(x)
+#define PLAN(h) reinterpret_cast<r3m::Plan*>(h)
+
+extern "C" {
+
+int r3m_abi_version(void) { return 1; }
+const char* r3m_last_error(void) { return g_err; }
+
+r3m_resnet_t r3m_resnet_create(int size, int frames) { return reinterpret_cast<r3m_resnet_t>(plan_create(size, frames)); }
+void r3m_resnet_destroy(r3m_resnet_t h) { if (h) plan_destroy(PLAN(h)); }
+int r3m_resnet_out_dim(r3m_resnet_t h) { return plan_out_dim(PLAN(h)); }
+long long r3m_resnet_num_params(r3m_resnet_t h) { return plan_num_params(PLAN(h)); }
+long long r3m_resnet_num_buffers(r3m_resnet_t h) { return plan_num_buffers(PLAN(h)); }
+long long r3m_resnet_arena_bytes(r3m_resnet_t h) { return plan_arena_floats(PLAN(h)) * 4; }
+int r3m_resnet_num_tensors(r3m_resnet_t h) { return plan_num_tensors(PLAN(h)); }
+int r3m_resnet_tensor_info(r3m_resnet_t h, int i, char* name, int name_cap, int* kind, long long* offset, int* ndim, int* shape4) {
+  return plan_tensor_info(PLAN(h), i, name, name_cap, kind, offset, ndim, shape4);
+}
+int r3m_resnet_stage_range(r3m_resnet_t h, int stage, long long* offset, long long* count) {
+  return plan_stage_range(PLAN(h), stage, offset, count);
+}
+int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, float* buffers, void* arena, float* h_out, int training,
+                       r3m_stream_t stream) {
+  R3M_REQUIRE(h && x && params && buffers && arena && h_out, "resnet_forward: null argument");
+  return plan_forward(*PLAN(h), x, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
+}
+int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
+                        int stage_end, int accumulate, r3m_stream_t stream) {
+  R3M_REQUIRE(h && dh && params && grads && arena, "resnet_backward: null argument");
+  R3M_REQUIRE(0 <= stage_begin && stage_begin <= stage_end && stage_end <= 4, "resnet_backward: stages [%d,%d)", stage_begin, stage_end);
+  return plan_backward(*PLAN(h), dh, params, grads, static_cast<float*>(arena), stage_begin, stage_end, accumulate, plan_gd(PLAN(h)),
+                       S(stream));
+}
+
+int r3m_conv2d_stats_rows(int N, int Hi, int Wi, int Co, int k, int stride, int pad) {
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  return gather_gemm_grid_m(N * Ho * Wo, Co);
+}
+int r3m_conv2d_fwd(const float* x, const float* w, float* y, float* stats, int N, int Hi, int Wi, int Ci, int Co, int k, int stride,
+                   int pad, r3m_stream_t stream) {
+  return conv_forward_launch(x, w, y, stats, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, stats ? EPI_STATS : 0, S(stream));
+}
+size_t r3m_conv2d_dgrad_workspace_bytes(int Ci, int Co, int k) { return (size_t)Ci * Co * k * k * 4; }
+int r3m_conv2d_dgrad(const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                     int k, int stride, int pad, r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k), "conv2d_dgrad: workspace too small");
+  float* Wt = static_cast<float*>(ws);
+  if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
+  return conv_dgrad_launch(dy, Wt, dx, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, S(stream));
+}
+size_t r3m_conv2d_wgrad_workspace_bytes(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+  return conv_wgrad_ws_floats(N, Hi, Wi, Ci, Co, k, stride, pad) * 4;
+}
+int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                     int k, int stride, int pad, int accumulate, r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_conv2d_wgrad_workspace_bytes(N, Hi, Wi, Ci, Co, k, stride, pad), "conv2d_wgrad: workspace too small");
+  return conv_wgrad_launch(x, dy, dw, static_cast<float*>(ws), N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, S(stream));
+}
+int r3m_stem_im2col(const float* x, float* col, int frames, r3m_stream_t stream) { return launch_stem_im2col(x, col, frames, S(stream)); }
+
+// workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
+static size_t bn_acc_off(long long rows, int C) {
+  size_t p = (size_t)bn_bwd_partial_rows(rows, C) * 2 * C * 4;
+  return (p + 255) / 256 * 256;
+}
+static size_t bn_c12_off(long long rows, int C) { return bn_acc_off(rows, C) + (size_t)64 * 2 * C * 8; }
+size_t r3m_bn_workspace_bytes(long long rows, int C) { return bn_c12_off(rows, C) + (size_t)2 * C * 4; }
+
+int r3m_bn_train_coeffs(const float* stats, int stats_rows, long long count, const float* gamma, const float* beta, float* rm,
+                        float* rv, float momentum, float eps, float* coef, void* ws, size_t ws_bytes, int C, r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= (size_t)64 * 2 * C * 8, "bn_train_coeffs: workspace too small");
+  double* acc = static_cast<double*>(ws);
+  if (int e = launch_bn_stats_reduce(stats, stats_rows, C, acc, S(stream))) return e;
+  return launch_bn_finalize_rows(acc, stats_rows, count, gamma, beta, rm, rv, momentum, eps, coef, coef + C, coef + 2 * C,
+                                 coef + 3 * C, C, S(stream));
+}
+int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* coef, int C,
+                       r3m_stream_t stream) {
+  return launch_bn_eval_coeffs(gamma, beta, rm, rv, eps, coef, coef + C, coef + 2 * C, coef + 3 * C, C, S(stream));
+}
+int r3m_bn_act_fwd(const float* y, const float* coef, const float* r, const float* y2, const float* coef2, float* z, long long rows,
+                   int C, int relu, r3m_stream_t stream) {
+  R3M_REQUIRE(!(r && y2), "bn_act_fwd: pass either r (identity) or y2/coef2 (downsample), not both");
+  if (y2) return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, y2, coef2 + 2 * C, coef2 + 3 * C, z, rows, C, relu, S(stream));
+  return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, r, nullptr, nullptr, z, rows, C, relu, S(stream));
+}
+int r3m_bn_bwd(const float* dz, const float* zmask, const float* y, const float* coef, float* dgamma, float* dbeta, float* dy,
+               void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_bn_workspace_bytes(rows, C), "bn_bwd: workspace too small (need %zu)", r3m_bn_workspace_bytes(rows, C));
+  float* partial = static_cast<float*>(ws);
+  double* acc = reinterpret_cast<double*>(static_cast<char*>(ws) + bn_acc_off(rows, C));
+  float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
+  const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
+  if (int e = launch_bn_bwd_reduce(dz, zmask, y, scale, shift, mean, invstd, partial, rows, C, S(stream))) return e;
+  const int prow = bn_bwd_partial_rows(rows, C);
+  if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
+  if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
+  return launch_bn_bwd_apply(dz, zmask, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, S(stream));
+}
+int r3m_maxpool_fwd(const float* z, float* p, unsigned char* am, int N, int Hi, int Wi, int C, r3m_stream_t stream) {
+  return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, S(stream));
+}
+int r3m_maxpool_bwd(const float* dp, const unsigned char* am, float* dz, int N, int Hi, int Wi, int C, r3m_stream_t stream) {
+  return launch_maxpool_bwd(dp, am, dz, N, Hi, Wi, C, S(stream));
+}
+int r3m_avgpool_fwd(const float* x, float* h, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_fwd(x, h, N, HW, C, S(stream)); }
+int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_bwd(dh, dx, N, HW, C, S(stream)); }
+
+int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu, r3m_stream_t stream) {
+  return conv_forward_launch(x, w, y, nullptr, bias, M, 1, 1, K, N, 1, 1, 0, (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0), S(stream));
+}
+
+size_t r3m_loss_workspace_bytes(int B) { return loss_workspace_floats(B) * 4; }
+int r3m_loss_tcn_lp(const float* alle, const int* perm, const int* iperm, float* dalle, void* ws, size_t ws_bytes, int B, int D,
+                    int l2dist, float l2w, float l1w, float tcnw, r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_loss_workspace_bytes(B), "loss: workspace too small");
+  return launch_tcn_lp_loss(alle, perm, iperm, dalle, static_cast<float*>(ws), B, D, l2dist, l2w, l1w, tcnw, S(stream));
+}
+int r3m_loss_lang_infonce(const float* scores, const float* mask, float* dscore, void* ws, size_t ws_bytes, int B, float langw,
+                          r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_loss_workspace_bytes(B), "loss: workspace too small");
+  return launch_lang_infonce(scores, mask, dscore, static_cast<float*>(ws), B, langw, S(stream));
+}
+int r3m_loss_finalize(void* ws, size_t ws_bytes, int B, int have_lang, float* metrics, float l2w, float l1w, float tcnw, float langw,
+                      r3m_stream_t stream) {
+  R3M_REQUIRE(ws_bytes >= r3m_loss_workspace_bytes(B), "loss: workspace too small");
+  return launch_loss_finalize(static_cast<float*>(ws), B, have_lang, metrics, l2w, l1w, tcnw, langw, S(stream));
+}
+
+int r3m_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
+                  long long step, float grad_scale, r3m_stream_t stream) {
+  return launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
+}
+
+}  // extern "C"

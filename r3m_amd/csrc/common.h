@@ -1,0 +1,111 @@
+// r3m_amd — internal declarations shared by the HIP translation units.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, fp32-input MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace r3m {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (thread-local message, C-ABI returns non-zero on failure) ----
+void set_last_error(const char* fmt, ...);
+int  check_launch(const char* what);  // hipGetLastError() -> 0 / code (+ message)
+
+#define R3M_REQUIRE(cond, ...)                  \
+  do {                                          \
+    if (!(cond)) {                              \
+      r3m::set_last_error(__VA_ARGS__);         \
+      return 1;                                 \
+    }                                           \
+  } while (0)
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- epilogue flags of the gather-GEMM (conv fwd / dgrad / linear) ----
+enum : int {
+  EPI_STATS      = 1,   // emit per-(row-block, column) sum / sum-of-squares partials (BatchNorm statistics)
+  EPI_ACCUM      = 2,   // out = acc + out_old
+  EPI_MASKED_ADD = 4,   // out = acc + add0 * (add1 > 0)   (residual gradient joining a dgrad)
+  EPI_BIAS       = 8,   // out = acc + bias[col]
+  EPI_RELU       = 16,  // out = max(out, 0)
+  EPI_BT_NK      = 32,  // (unused by conv) reserved
+};
+
+constexpr int MAX_TAPS = 49;
+
+// One launch of the gather-GEMM:  out[row(m), :] = sum_t  in[pix(m) + (dy_t, dx_t), :] * B[:, wt_t, :]^T
+struct GatherGemmParams {
+  const float* A;      // input activations, NHWC [N, Hi, Wi, Ci]
+  const float* B;      // weights [Nc][T][Ci]  (row = output column, K contiguous)
+  float* out;          // output activations, NHWC [N, Ho, Wo, Nc]
+  const float* add0;   // EPI_MASKED_ADD: gradient tensor, same shape as out
+  const float* add1;   // EPI_MASKED_ADD: mask source (post-ReLU activation), same shape as out
+  const float* bias;   // EPI_BIAS: [Nc]
+  float* stats;        // EPI_STATS: [gridM][2][Nc]
+  int N, Hi, Wi, Ci;
+  int Hg, Wg;          // GEMM row grid per image: m = (n*Hg + gy)*Wg + gx
+  int Ho, Wo, Nc;      // output tensor dims (Nc = GEMM N)
+  int is;              // input pixel = (gy*is + dy_t, gx*is + dx_t)
+  int os, ooy, oox;    // output pixel = (gy*os + ooy, gx*os + oox)
+  int M;               // N*Hg*Wg
+  int T;               // taps in the weight tensor (B row stride = T*Ci)
+  int ntaps;           // taps visited by this launch
+  int flags;
+  int simple_rows;     // 1: 1x1 / stride 1 / no padding -> input row offset = m*Ci (no pixel decode)
+  signed char dy[MAX_TAPS];
+  signed char dx[MAX_TAPS];
+  unsigned char wt[MAX_TAPS];
+};
+
+struct WgradParams {
+  const float* dY;   // [M][Co]  (NHWC rows of the conv output gradient)
+  const float* X;    // conv input, NHWC [N, Hi, Wi, Ci]
+  float* out;        // [splitK][Co][T][Ci] partials (or the gradient itself when splitK == 1)
+  int N, Hi, Wi, Ci;
+  int Ho, Wo, Co;
+  int KH, KW, stride, pad;
+  int M;               // N*Ho*Wo
+  int rows_per_split;  // multiple of 32
+  int simple_rows;     // 1x1 stride-1: X row offset = m*Ci
+  int tilesN;          // ceil(Ci / BN)
+};
+
+// ---- launchers (conv.hip) ----
+int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
+int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher will use (stats partial rows)
+int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
+int wgrad_pick_split(int M, int Co, int Ci, int T);
+int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s);
+int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
+int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s);
+int launch_pack_stem_w(const float* w147, float* w160, hipStream_t s);
+int launch_unpack_stem_dw(const float* dw160, float* dw147, int accumulate, hipStream_t s);
+
+// ---- launchers (bn.hip) ----
+int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /*[<=64][2][C]*/, hipStream_t s);
+int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                            float* invstd, float* scale, float* shift, int C, hipStream_t s);
+int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s);
+int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
+                      const float* shift2, float* Z, long long rows, int C, int relu, hipStream_t s);
+int bn_bwd_partial_rows(long long rows, int C);
+int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float* partials, long long rows, int C, hipStream_t s);
+int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
+                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s);
+int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
+                        long long rows, int C, hipStream_t s);
+int launch_maxpool_fwd(const float* Z, float* P, unsigned char* amax, int N, int Hi, int Wi, int C, hipStream_t s);
+int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, int N, int Hi, int Wi, int C, hipStream_t s);
+int launch_avgpool_fwd(const float* X, float* H, int N, int HW, int C, hipStream_t s);
+int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStream_t s);
+
+// ---- launchers (adam.hip / loss.hip) declared in their own section of the C ABI ----
+
+}  // namespace r3m

@@ -1,0 +1,500 @@
+// r3m_amd — the ResNet-18/34/50 encoder engine: a native plan (layer table + HBM arena layout) and the forward /
+// backward launch sequences, all on one caller-supplied HIP stream. This is the from-scratch counterpart of what the
+// reference obtains from torchvision.models.resnet{18,34,50}(pretrained=False) with fc = Identity, driven by
+// R3M.forward (/root/reference/r3m/models/models_r3m.py:44-52,62,84-100) and autograd's backward
+// (/root/reference/r3m/trainer.py:157). Architecture restated from SURVEY.md Appendix A (torchvision 0.8.2 is not
+// vendored): stem 7x7/2 + BN + ReLU + maxpool 3x3/2, BasicBlock [2,2,2,2] / [3,4,6,3] or Bottleneck v1.5 [3,4,6,3],
+// global average pool, flatten.
+//
+// HBM layout: activations NHWC fp32 in ONE arena owned by the caller (offsets fixed at plan creation, sized for the
+// frame count F); parameters and gradients are two flat fp32 buffers in torchvision parameter order with conv weights
+// stored OHWI (= logical OIHW tensors with channels_last strides, so state-dict interchange needs no copy kernels).
+#include "common.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace r3m {
+
+struct ConvSpec {
+  std::string name;      // e.g. "layer1.0.conv1" ; BatchNorm is name_bn
+  std::string bn_name;
+  int Ci, Co, k, stride, pad;
+  int Hi, Wi, Ho, Wo;
+  long long w_off, gamma_off, beta_off;   // flat parameter / gradient buffer (floats)
+  long long rm_off, rv_off;               // flat running-statistics buffer (floats)
+  long long Y_off;                        // arena: raw conv output [F,Ho,Wo,Co]
+  long long Z_off;                        // arena: activated output, -1 when the block epilogue produces it
+  long long coef_off;                     // arena: mean, invstd, scale, shift, c1, c2  (6*Co floats)
+  int stats_rows;                         // row blocks of the forward GEMM (BatchNorm partials)
+};
+
+struct BlockSpec {
+  int conv[3];
+  int nconv;
+  int ds;                 // downsample conv index or -1
+  long long in_off;       // arena offset of the block input
+  long long out_off;      // arena offset of the block output
+  int Ho, Wo, Co;
+  int stage;              // 0..3 = layer1..layer4
+};
+
+struct TensorInfo {
+  std::string name;
+  int kind;               // 0 conv weight, 1 bn weight, 2 bn bias, 3 running_mean, 4 running_var
+  long long offset;       // floats, in the params buffer (kind 0-2) or the buffers buffer (kind 3-4)
+  int shape[4];           // logical shape (conv: O, I, kh, kw)
+  int ndim;
+};
+
+struct Plan {
+  int size, F, D;
+  std::vector<ConvSpec> convs;
+  std::vector<BlockSpec> blocks;
+  std::vector<TensorInfo> tensors;
+  long long n_params = 0, n_buffers = 0;
+  long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
+  // arena offsets (floats)
+  long long col_off, w160_off, dw160_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
+  long long G_off[4];
+  long long arena_floats = 0;
+  long long gmax = 0;
+  int last_training = 1;
+  int gd = 0;             // which G buffer holds the running output-gradient between backward stages
+};
+
+static long long align64(long long x) { return (x + 63) / 64 * 64; }
+
+static int add_conv(Plan& P, const std::string& name, const std::string& bn, int Ci, int Co, int k, int stride, int pad,
+                    int Hi, int Wi) {
+  ConvSpec c;
+  c.name = name; c.bn_name = bn;
+  c.Ci = Ci; c.Co = Co; c.k = k; c.stride = stride; c.pad = pad; c.Hi = Hi; c.Wi = Wi;
+  c.Ho = (Hi + 2 * pad - k) / stride + 1;
+  c.Wo = (Wi + 2 * pad - k) / stride + 1;
+  c.w_off = P.n_params;
+  P.n_params += (long long)Co * Ci * k * k;
+  c.gamma_off = P.n_params; P.n_params += Co;
+  c.beta_off = P.n_params; P.n_params += Co;
+  c.rm_off = P.n_buffers; P.n_buffers += Co;
+  c.rv_off = P.n_buffers; P.n_buffers += Co;
+  TensorInfo t;
+  t.name = name + ".weight"; t.kind = 0; t.offset = c.w_off; t.ndim = 4;
+  t.shape[0] = Co; t.shape[1] = Ci; t.shape[2] = k; t.shape[3] = k;
+  P.tensors.push_back(t);
+  t.ndim = 1; t.shape[0] = Co; t.shape[1] = t.shape[2] = t.shape[3] = 1;
+  t.name = bn + ".weight"; t.kind = 1; t.offset = c.gamma_off; P.tensors.push_back(t);
+  t.name = bn + ".bias"; t.kind = 2; t.offset = c.beta_off; P.tensors.push_back(t);
+  t.name = bn + ".running_mean"; t.kind = 3; t.offset = c.rm_off; P.tensors.push_back(t);
+  t.name = bn + ".running_var"; t.kind = 4; t.offset = c.rv_off; P.tensors.push_back(t);
+  c.Y_off = c.Z_off = c.coef_off = -1;
+  c.stats_rows = 0;
+  P.convs.push_back(c);
+  return (int)P.convs.size() - 1;
+}
+
+Plan* plan_create(int size, int F) {
+  if (size != 18 && size != 34 && size != 50) { set_last_error("resnet: unsupported size %d (18, 34, 50)", size); return nullptr; }
+  if (F < 1) { set_last_error("resnet: F=%d must be >= 1", F); return nullptr; }
+  Plan* Pp = new Plan();
+  Plan& P = *Pp;
+  P.size = size; P.F = F;
+  const bool bottleneck = (size == 50);
+  const int expansion = bottleneck ? 4 : 1;
+  const int nblk[4] = {size == 18 ? 2 : 3, size == 18 ? 2 : 4, size == 18 ? 2 : 6, size == 18 ? 2 : 3};
+  P.D = 512 * expansion;
+
+  // ---- layer table in torchvision parameter order ----
+  add_conv(P, "conv1", "bn1", 3, 64, 7, 2, 3, 224, 224);
+  P.stage_param_begin[0] = 0;
+  int inC = 64, H = 56;
+  for (int L = 0; L < 4; ++L) {
+    const int planes = 64 << L;
+    if (L > 0) P.stage_param_begin[L] = P.n_params;
+    for (int b = 0; b < nblk[L]; ++b) {
+      const int stride = (b == 0 && L > 0) ? 2 : 1;
+      char pre[64];
+      snprintf(pre, sizeof pre, "layer%d.%d", L + 1, b);
+      const std::string p(pre);
+      BlockSpec B;
+      B.stage = L; B.ds = -1;
+      const int Hout = H / stride;
+      if (bottleneck) {
+        B.nconv = 3;
+        B.conv[0] = add_conv(P, p + ".conv1", p + ".bn1", inC, planes, 1, 1, 0, H, H);
+        B.conv[1] = add_conv(P, p + ".conv2", p + ".bn2", planes, planes, 3, stride, 1, H, H);
+        B.conv[2] = add_conv(P, p + ".conv3", p + ".bn3", planes, planes * 4, 1, 1, 0, Hout, Hout);
+      } else {
+        B.nconv = 2;
+        B.conv[0] = add_conv(P, p + ".conv1", p + ".bn1", inC, planes, 3, stride, 1, H, H);
+        B.conv[1] = add_conv(P, p + ".conv2", p + ".bn2", planes, planes, 3, 1, 1, Hout, Hout);
+        B.conv[2] = -1;
+      }
+      if (stride != 1 || inC != planes * expansion)
+        B.ds = add_conv(P, p + ".downsample.0", p + ".downsample.1", inC, planes * expansion, 1, stride, 0, H, H);
+      B.Ho = B.Wo = Hout; B.Co = planes * expansion;
+      P.blocks.push_back(B);
+      inC = planes * expansion; H = Hout;
+    }
+  }
+  P.stage_param_begin[4] = P.n_params;
+
+  // ---- arena layout ----
+  long long off = 0;
+  auto take = [&](long long n) { long long o = off; off = align64(off + n); return o; };
+  const long long Fll = F;
+  P.col_off = take(Fll * 112 * 112 * 160);
+  P.w160_off = take(64 * 160);
+  P.dw160_off = take(64 * 160);
+  long long gmax = 0, partial_max = 0, wmax = 0, wgp_max = 0;
+  auto act_elems = [&](const ConvSpec& c) { return Fll * c.Ho * c.Wo * c.Co; };
+  for (size_t i = 0; i < P.convs.size(); ++i) {
+    ConvSpec& c = P.convs[i];
+    c.Y_off = take(act_elems(c));
+    c.coef_off = take(6LL * c.Co);
+    if (act_elems(c) > gmax) gmax = act_elems(c);
+    const int M = F * c.Ho * c.Wo;
+    c.stats_rows = gather_gemm_grid_m(M, c.Co);
+    long long pr = (long long)c.stats_rows * 2 * c.Co;
+    if (pr > partial_max) partial_max = pr;
+    pr = (long long)bn_bwd_partial_rows(M, c.Co) * 2 * c.Co;
+    if (pr > partial_max) partial_max = pr;
+    const long long welems = (i == 0) ? 64LL * 160 : (long long)c.Co * c.k * c.k * c.Ci;
+    if (welems > wmax) wmax = welems;
+    const int split = (i == 0) ? wgrad_pick_split(M, 64, 160, 1) : wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
+    if (welems * split > wgp_max) wgp_max = welems * split;
+  }
+  // stem: Z0 (pre-pool activation), P0 (pooled), argmax bytes
+  P.convs[0].Z_off = take(act_elems(P.convs[0]));
+  P.P0_off = take(Fll * 56 * 56 * 64);
+  P.amax_off = take((Fll * 56 * 56 * 64 + 3) / 4);
+  long long cur_in = P.P0_off;
+  for (auto& B : P.blocks) {
+    B.in_off = cur_in;
+    for (int j = 0; j < B.nconv - 1; ++j) P.convs[B.conv[j]].Z_off = take(act_elems(P.convs[B.conv[j]]));
+    B.out_off = take(Fll * B.Ho * B.Wo * B.Co);
+    cur_in = B.out_off;
+  }
+  P.partial_off = take(partial_max);
+  P.acc_off = take(64LL * 2 * 2048 * 2);  // doubles: 64 slices x 2 x Cmax, in float units x2
+  P.wt_off = take(wmax);
+  P.wgp_off = take(wgp_max);
+  P.gmax = gmax;
+  for (int g = 0; g < 4; ++g) P.G_off[g] = take(gmax);
+  P.arena_floats = off;
+  return Pp;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct Ctx {
+  Plan& P;
+  const float* params;
+  float* grads;
+  float* bufs;
+  float* arena;
+  hipStream_t s;
+  int training;
+  int accumulate;
+};
+
+static void fill_taps_fwd(GatherGemmParams& g, int k, int pad) {
+  int t = 0;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      g.dy[t] = (signed char)(kh - pad); g.dx[t] = (signed char)(kw - pad); g.wt[t] = (unsigned char)(kh * k + kw); ++t;
+    }
+  g.ntaps = t;
+}
+
+int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
+                        int Co, int k, int stride, int pad, int flags, hipStream_t s) {
+  GatherGemmParams g;
+  memset(&g, 0, sizeof g);
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  g.A = X; g.B = W; g.out = Y; g.stats = stats; g.bias = bias;
+  g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
+  g.Hg = Ho; g.Wg = Wo; g.Ho = Ho; g.Wo = Wo; g.Nc = Co;
+  g.is = stride; g.os = 1; g.ooy = 0; g.oox = 0;
+  g.M = N * Ho * Wo;
+  g.T = k * k;
+  fill_taps_fwd(g, k, pad);
+  g.flags = flags;
+  g.simple_rows = (k == 1 && stride == 1 && pad == 0) ? 1 : 0;
+  return launch_gather_gemm(g, s);
+}
+
+// dX[N,Hi,Wi,Ci] = dgrad of conv(k, stride, pad) given dY[N,Ho,Wo,Co] and Wt[Ci][k*k][Co]
+int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, int N, int Hi, int Wi,
+                      int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s) {
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  R3M_REQUIRE(stride == 1 || stride == 2, "dgrad: stride %d", stride);
+  GatherGemmParams g;
+  memset(&g, 0, sizeof g);
+  g.A = dY; g.B = Wt; g.out = dX; g.add0 = add0; g.add1 = add1;
+  g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co;   // the GEMM "input" is dY
+  g.Ho = Hi; g.Wo = Wi; g.Nc = Ci;
+  g.is = 1; g.T = k * k; g.flags = flags;
+  if (stride == 1) {
+    g.Hg = Hi; g.Wg = Wi; g.os = 1; g.ooy = g.oox = 0;
+    g.M = N * Hi * Wi;
+    int t = 0;
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) {
+        g.dy[t] = (signed char)(pad - kh); g.dx[t] = (signed char)(pad - kw); g.wt[t] = (unsigned char)(kh * k + kw); ++t;
+      }
+    g.ntaps = t;
+    g.simple_rows = (k == 1 && pad == 0) ? 1 : 0;
+    return launch_gather_gemm(g, s);
+  }
+  // stride 2: one launch per output parity class; class (py,px) only sees taps with (py+pad-kh), (px+pad-kw) even
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      GatherGemmParams c = g;
+      c.Hg = (Hi - py + 1) / 2; c.Wg = (Wi - px + 1) / 2;
+      if (c.Hg <= 0 || c.Wg <= 0) continue;
+      c.os = 2; c.ooy = py; c.oox = px;
+      c.M = N * c.Hg * c.Wg;
+      int t = 0;
+      for (int kh = 0; kh < k; ++kh) {
+        if ((py + pad - kh) & 1) continue;
+        for (int kw = 0; kw < k; ++kw) {
+          if ((px + pad - kw) & 1) continue;
+          c.dy[t] = (signed char)((py + pad - kh) / 2); c.dx[t] = (signed char)((px + pad - kw) / 2);
+          c.wt[t] = (unsigned char)(kh * k + kw); ++t;
+        }
+      }
+      c.ntaps = t;
+      c.simple_rows = 0;
+      if (t == 0 && (flags & EPI_ACCUM) && !(flags & EPI_MASKED_ADD)) continue;  // nothing to add
+      if (int e = launch_gather_gemm(c, s)) return e;
+    }
+  return 0;
+}
+
+int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
+                      int stride, int pad, int accumulate, hipStream_t s) {
+  WgradParams w;
+  memset(&w, 0, sizeof w);
+  w.Ho = (Hi + 2 * pad - k) / stride + 1; w.Wo = (Wi + 2 * pad - k) / stride + 1;
+  w.dY = dY; w.X = X; w.out = partial_ws;
+  w.N = N; w.Hi = Hi; w.Wi = Wi; w.Ci = Ci; w.Co = Co;
+  w.KH = w.KW = k; w.stride = stride; w.pad = pad;
+  w.M = N * w.Ho * w.Wo;
+  w.simple_rows = (k == 1 && stride == 1 && pad == 0) ? 1 : 0;
+  const int split = wgrad_pick_split(w.M, Co, Ci, k * k);
+  if (int e = launch_wgrad(w, split, s)) return e;
+  return launch_wgrad_reduce(partial_ws, dW, (long long)Co * k * k * Ci, split, accumulate, s);
+}
+
+size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  const int split = wgrad_pick_split(N * Ho * Wo, Co, Ci, k * k);
+  return (size_t)split * Co * k * k * Ci;
+}
+
+#define TRY(x)              \
+  do {                      \
+    if (int e_ = (x)) return e_; \
+  } while (0)
+
+static float* coef(Ctx& c, const ConvSpec& L, int which) { return c.arena + L.coef_off + (long long)which * L.Co; }
+
+// conv -> (training: batch statistics -> coefficients | eval: running statistics -> coefficients)
+static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float* W, int Ci_eff, int k_eff, int stride_eff,
+                          int pad_eff, int Hi_eff, int Wi_eff, int N_eff) {
+  Plan& P = c.P;
+  float* Y = c.arena + L.Y_off;
+  float* partial = c.arena + P.partial_off;
+  double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
+  TRY(conv_forward_launch(X, W, Y, partial, nullptr, N_eff, Hi_eff, Wi_eff, Ci_eff, L.Co, k_eff, stride_eff, pad_eff,
+                          c.training ? EPI_STATS : 0, c.s));
+  const float* gamma = c.params + L.gamma_off;
+  const float* beta = c.params + L.beta_off;
+  if (c.training) {
+    const long long count = (long long)P.F * L.Ho * L.Wo;
+    TRY(launch_bn_stats_reduce(partial, L.stats_rows, L.Co, acc, c.s));
+    TRY(launch_bn_finalize_rows(acc, L.stats_rows, count, gamma, beta, c.bufs + L.rm_off, c.bufs + L.rv_off, 0.1f, 1e-5f,
+                                coef(c, L, 0), coef(c, L, 1), coef(c, L, 2), coef(c, L, 3), L.Co, c.s));
+  } else {
+    TRY(launch_bn_eval_coeffs(gamma, beta, c.bufs + L.rm_off, c.bufs + L.rv_off, 1e-5f, coef(c, L, 0), coef(c, L, 1),
+                              coef(c, L, 2), coef(c, L, 3), L.Co, c.s));
+  }
+  return 0;
+}
+
+static int conv_bn(Ctx& c, const ConvSpec& L, const float* X) {
+  return conv_bn_coeffs(c, L, X, c.params + L.w_off, L.Ci, L.k, L.stride, L.pad, L.Hi, L.Wi, c.P.F);
+}
+
+int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
+                 hipStream_t s) {
+  Ctx c{P, params, nullptr, bufs, arena, s, training, 0};
+  P.last_training = training;
+  const int F = P.F;
+  // ---- stem ----
+  const ConvSpec& L0 = P.convs[0];
+  float* col = arena + P.col_off;
+  float* w160 = arena + P.w160_off;
+  TRY(launch_stem_im2col(x_nchw, col, F, s));
+  TRY(launch_pack_stem_w(params + L0.w_off, w160, s));
+  // conv1 as a 1x1 GEMM over the 160-wide patch rows; geometry "N = F*112*112 pixels of 1x1"
+  TRY(conv_bn_coeffs(c, L0, col, w160, 160, 1, 1, 0, 112, 112, F));
+  float* Z0 = arena + L0.Z_off;
+  const long long rows0 = (long long)F * 112 * 112;
+  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, s));
+  TRY(launch_maxpool_fwd(Z0, arena + P.P0_off, reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, s));
+  // ---- residual stages ----
+  for (const BlockSpec& B : P.blocks) {
+    const float* Xin = arena + B.in_off;
+    const float* cur = Xin;
+    for (int j = 0; j < B.nconv; ++j) {
+      const ConvSpec& L = P.convs[B.conv[j]];
+      TRY(conv_bn(c, L, cur));
+      if (j < B.nconv - 1) {
+        const long long rows = (long long)F * L.Ho * L.Wo;
+        TRY(launch_bn_act_fwd(arena + L.Y_off, coef(c, L, 2), coef(c, L, 3), nullptr, nullptr, nullptr, arena + L.Z_off, rows,
+                              L.Co, 1, s));
+        cur = arena + L.Z_off;
+      }
+    }
+    const ConvSpec& LL = P.convs[B.conv[B.nconv - 1]];
+    const long long rows = (long long)F * B.Ho * B.Wo;
+    if (B.ds >= 0) {
+      const ConvSpec& Ld = P.convs[B.ds];
+      TRY(conv_bn(c, Ld, Xin));
+      TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), arena + Ld.Y_off, coef(c, Ld, 2), coef(c, Ld, 3),
+                            arena + B.out_off, rows, B.Co, 1, s));
+    } else {
+      TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), Xin, nullptr, nullptr, arena + B.out_off, rows,
+                            B.Co, 1, s));
+    }
+  }
+  const BlockSpec& last = P.blocks.back();
+  TRY(launch_avgpool_fwd(arena + last.out_off, h_out, F, last.Ho * last.Wo, last.Co, s));
+  return 0;
+}
+
+// BatchNorm(+ReLU / residual mask) backward of layer L: dZ -> dY, parameter gradients into the flat gradient buffer
+static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const float* Zmask, float* dY) {
+  Plan& P = c.P;
+  const long long rows = (long long)P.F * L.Ho * L.Wo;
+  float* partial = c.arena + P.partial_off;
+  double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
+  const float* Y = c.arena + L.Y_off;
+  TRY(launch_bn_bwd_reduce(dZ, Zmask, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.s));
+  const int prow = bn_bwd_partial_rows(rows, L.Co);
+  TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
+  TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
+                                  coef(c, L, 5), c.accumulate, L.Co, c.s));
+  TRY(launch_bn_bwd_apply(dZ, Zmask, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
+                          dY, rows, L.Co, c.s));
+  return 0;
+}
+
+static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
+  return conv_wgrad_launch(X, dY, c.grads + L.w_off, c.arena + c.P.wgp_off, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad,
+                           c.accumulate, c.s);
+}
+
+static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const float* add1) {
+  float* Wt = c.arena + c.P.wt_off;
+  TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
+  return conv_dgrad_launch(dY, Wt, dX, add0, add1, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.s);
+}
+
+// Backward stages: 0 = avgpool + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem. The gradient w.r.t. the current
+// block output lives in arena buffer G[gd]; `gd` is carried across calls in *gd_io so stages can be issued one by one
+// (the data-parallel wrapper launches the RCCL all-reduce of a finished stage's gradient slice in between).
+int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
+                  int accumulate, int* gd_io, hipStream_t s) {
+  Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate};
+  const int F = P.F;
+  int gd = *gd_io;
+  auto G = [&](int i) { return arena + P.G_off[i & 3]; };
+  for (int st = stage_begin; st < stage_end; ++st) {
+    const int layer = 3 - st;
+    if (st == 0) {
+      const BlockSpec& last = P.blocks.back();
+      gd = 0;
+      TRY(launch_avgpool_bwd(dh, G(gd), F, last.Ho * last.Wo, last.Co, s));
+    }
+    for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
+      const BlockSpec& B = P.blocks[bi];
+      if (B.stage != layer) continue;
+      const float* dOut = G(gd);
+      const float* Out = arena + B.out_off;
+      const float* Xin = arena + B.in_off;
+      float* Ga = G(gd + 1);
+      float* Gb = G(gd + 2);
+      float* Gc = G(gd + 3);
+      // last conv of the block: its BatchNorm output joined the residual add, mask comes from the block output
+      const float* dz = dOut;
+      const float* zmask = Out;
+      for (int j = B.nconv - 1; j >= 1; --j) {
+        const ConvSpec& L = P.convs[B.conv[j]];
+        const ConvSpec& Lprev = P.convs[B.conv[j - 1]];
+        TRY(bn_backward(c, L, dz, zmask, Ga));
+        TRY(wgrad(c, L, arena + Lprev.Z_off, Ga));
+        TRY(dgrad(c, L, Ga, Gb, 0, nullptr, nullptr));
+        dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward (-> Ga) before dgrad rewrites it
+      }
+      const ConvSpec& L1 = P.convs[B.conv[0]];
+      TRY(bn_backward(c, L1, dz, zmask, Ga));
+      TRY(wgrad(c, L1, Xin, Ga));
+      if (B.ds >= 0) {
+        const ConvSpec& Ld = P.convs[B.ds];
+        TRY(dgrad(c, L1, Ga, Gc, 0, nullptr, nullptr));
+        TRY(bn_backward(c, Ld, dOut, Out, Gb));
+        TRY(wgrad(c, Ld, Xin, Gb));
+        TRY(dgrad(c, Ld, Gb, Gc, EPI_ACCUM, nullptr, nullptr));
+      } else {
+        TRY(dgrad(c, L1, Ga, Gc, EPI_MASKED_ADD, dOut, Out));
+      }
+      gd = (gd + 3) & 3;  // Gc becomes the gradient of the previous block's output
+    }
+    if (st == 3) {
+      // stem: maxpool -> BN+ReLU -> conv1 (no input gradient)
+      const ConvSpec& L0 = P.convs[0];
+      float* Ga = G(gd + 1);
+      float* Gb = G(gd + 2);
+      TRY(launch_maxpool_bwd(G(gd), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Ga, F, 112, 112, 64, s));
+      TRY(bn_backward(c, L0, Ga, nullptr, Gb));
+      float* dw160 = arena + P.dw160_off;
+      TRY(conv_wgrad_launch(arena + P.col_off, Gb, dw160, arena + P.wgp_off, F * 112 * 112, 1, 1, 160, 64, 1, 1, 0, 0, s));
+      TRY(launch_unpack_stem_dw(dw160, grads + L0.w_off, accumulate, s));
+    }
+  }
+  *gd_io = gd;
+  return 0;
+}
+
+// ---- accessors for the C ABI ----
+int plan_out_dim(Plan* P) { return P->D; }
+long long plan_num_params(Plan* P) { return P->n_params; }
+long long plan_num_buffers(Plan* P) { return P->n_buffers; }
+long long plan_arena_floats(Plan* P) { return P->arena_floats; }
+int plan_num_tensors(Plan* P) { return (int)P->tensors.size(); }
+int plan_tensor_info(Plan* P, int i, char* name, int cap, int* kind, long long* offset, int* ndim, int* shape4) {
+  R3M_REQUIRE(i >= 0 && i < (int)P->tensors.size(), "tensor_info: index %d out of range", i);
+  const TensorInfo& t = P->tensors[i];
+  if (name && cap > 0) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (ndim) *ndim = t.ndim;
+  if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+  return 0;
+}
+// backward stage s covers layer (4 - s); stage 3 also covers the stem (its params sit before layer1's)
+int plan_stage_range(Plan* P, int stage, long long* off, long long* count) {
+  R3M_REQUIRE(stage >= 0 && stage < 4, "stage_range: stage %d", stage);
+  const int L = 3 - stage;
+  const long long b = P->stage_param_begin[L], e = P->stage_param_begin[L + 1];
+  if (off) *off = b;
+  if (count) *count = e - b;
+  return 0;
+}
+void plan_destroy(Plan* P) { delete P; }
+int* plan_gd(Plan* P) { return &P->gd; }
+
+}  // namespace r3m
