@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric: encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W                      # one process
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W    # one rank per GPU
+
+A step = one R3M pre-training step on one batch of synthetic clips already resident in HBM: encoder forward over 5B
+frames, LP + TCN loss, encoder backward (+ RCCL gradient all-reduce overlapped with it when N > 1), fused Adam — exactly
+Trainer.update (BASELINE config 2: "ResNet-50 encoder fwd+bwd bs=256 fp32, TCN loss only, synthetic frames").
+"bs=256" is 256 clips per GPU = 1280 frames per GPU (the reference's batch_size counts clips).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GFLOP_PER_FRAME = {50: 24.2868, 34: 21.7435, 18: 10.6453}   # algorithmic conv FLOPs fwd+bwd, SURVEY.md §8(d)
+PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
+          "wgrad_64x64"]
+
+
+def cpu_baseline(size, clips, seconds_budget=25.0):
+    """The oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this box's host cores, bounded sample."""
+    from oracle import r3m_ref
+    torch.manual_seed(1)
+    n_thr = os.cpu_count() or 1
+    torch.set_num_threads(n_thr)
+    ref = r3m_ref.R3MRef(size=size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    g = torch.Generator().manual_seed(1234)
+    frames = torch.randint(0, 256, (clips, 5, 3, 224, 224), generator=g).float()
+    perms = torch.stack([torch.randperm(clips) for _ in range(6)])
+    r3m_ref.train_step_ref(ref, frames, tcn_perm=perms)   # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
+        t0 = time.time()
+        r3m_ref.train_step_ref(ref, frames, tcn_perm=perms)
+        times.append(time.time() - t0)
+        if time.time() > t_end and len(times) >= 3:
+            break
+    best = min(times)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(clips * 5 / best, 2), "unit": "frames/s", "cores": n_thr, "kind": "port",
+            "sample": f"oracle/r3m_ref.py train step (ResNet-{size} fwd+loss+bwd+Adam, fp32, torch {torch.__version__} CPU), "
+                      f"{clips} clips = {clips*5} frames, best of {len(times)} after 1 warm-up, {n_thr} threads on {cpu_model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=50)
+    ap.add_argument("--clips-per-gpu", type=int, default=256, help="clips per GPU (5 frames each); BASELINE bs=256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU (WORLD_SIZE={world}); launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from r3m_amd import R3M, _lib
+    from r3m_amd.parallel import make_network_wrapper
+    from r3m_amd.trainer import Trainer
+    L = _lib.lib()
+
+    torch.manual_seed(1)                               # config_rep.yaml seed
+    B = args.clips_per_gpu
+    model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0, l2dist=True, bs=B)
+    model = model.to(dev)
+    net = make_network_wrapper(model)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
+    langs = [""] * B
+    trainer = Trainer(eval_freq=10 ** 9)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.update(net, (frames, langs), i)
+    L.r3m_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        metrics, _ = trainer.update(net, (frames, langs), args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms, launches, flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
+    _lib.check(L.r3m_profile_collect(ms, launches, flops), "profile_collect")
+    L.r3m_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        F_total = 5 * B * world
+        fps = F_total * args.steps / dt
+        kernels = []
+        for k in range(4):
+            if launches[k]:
+                kernels.append({"kernel": KCLASS[k], "launches_per_step": launches[k] / args.steps,
+                                "avg_launch_ms": ms[k] / launches[k], "ms_per_step": ms[k] / args.steps,
+                                "tflops": flops[k] / (ms[k] * 1e-3) / 1e12})
+        dom = max(range(4), key=lambda k: ms[k])
+        ach = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("dominant_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU" if args.size == 50 and B == 256 else
+                      f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2 bs={B}/GPU",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), fp32, "
+                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight=0 l1=l2=1e-5 l2dist",
+                       "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
+                       "final_full_loss": metrics["full_loss"]},
+            "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
+                         "algorithmic_gflop_per_launch": round(flops[dom] / max(1, launches[dom]) / 1e9, 3),
+                         "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[args.size] / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "kernels": kernels},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_clips)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

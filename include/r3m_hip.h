@@ -23,6 +23,13 @@ typedef struct r3m_resnet* r3m_resnet_t;
 int r3m_abi_version(void);
 const char* r3m_last_error(void);
 
+/* Measurement aid for bench.py (not part of the replaced reference surface): while enabled, every conv GEMM launch is
+ * bracketed by HIP events on its own stream. Classes: 0 gather-GEMM 128x128 tile (conv fwd/dgrad, Linear), 1 gather-GEMM
+ * 256x64 tile (64-channel layers), 2 wgrad 128x128, 3 wgrad 64x64. collect() sums elapsed ms / launches / algorithmic
+ * FLOPs per class since the last collect (arrays of 4) and resets. */
+void r3m_profile_enable(int on);
+int r3m_profile_collect(double* ms, long long* launches, double* flops);
+
 /* ---------------- encoder engine -----------------------------------------------------------------------------
  * Replaces torchvision.models.resnet{18,34,50}(pretrained=False) with fc=Identity as built by R3M.__init__
  * (r3m/models/models_r3m.py:44-52,62-63) and run by R3M.forward (models_r3m.py:84-100: x/255 -> Normalize -> convnet);

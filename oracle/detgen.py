@@ -1,0 +1,61 @@
+"""Deterministic, platform-independent tensor generator (integer hash of (name, flat index) -> float), so that golden
+fixtures can be regenerated bit-identically on the GPU box without shipping 45-94 MB of weights. Test infrastructure."""
+import zlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def unit(name, n):
+    """n floats in [0,1), float64, function of (name, index) only."""
+    seed = np.uint64((zlib.crc32(name.encode("utf-8")) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) + seed
+        h = _splitmix(_splitmix(idx))
+    return (h >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def uniform(name, shape, lo, hi):
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * unit(name, n)).astype(np.float32).reshape(shape)
+
+
+def frames(name, shape):
+    """uint8-valued frames as float32 in 0..255 (what the reference's loader yields, data_loaders.py:98-104)."""
+    n = int(np.prod(shape))
+    return np.floor(unit(name, n) * 256.0).astype(np.float32).reshape(shape)
+
+
+def permutation(name, n):
+    return np.argsort(unit(name, n), kind="stable").astype(np.int64)
+
+
+def resnet_state_dict(named_shapes, tag="w"):
+    """Kaiming-scaled uniform conv weights, non-trivial BatchNorm affine and running statistics.
+    named_shapes: iterable of (key, shape) in state-dict order (keys as in torchvision, no prefix)."""
+    out = {}
+    for key, shape in named_shapes:
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.zeros((), dtype=np.int64)
+        elif key.endswith("running_mean"):
+            out[key] = uniform(tag + key, shape, -0.1, 0.1)
+        elif key.endswith("running_var"):
+            out[key] = uniform(tag + key, shape, 0.5, 1.5)
+        elif len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            a = float(np.sqrt(3.0) * np.sqrt(2.0 / fan_out))
+            out[key] = uniform(tag + key, shape, -a, a)
+        elif key.endswith(".weight"):
+            out[key] = uniform(tag + key, shape, 0.5, 1.5)
+        else:
+            out[key] = uniform(tag + key, shape, -0.2, 0.2)
+    return out

@@ -1,0 +1,104 @@
+"""ctypes binding of libr3m_hip.so (C ABI: include/r3m_hip.h).
+
+The HIP library is the product: there is NO fallback. `lib()` raises if the shared object is missing, and every
+wrapper raises RuntimeError(r3m_last_error()) on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libr3m_hip.so")
+
+_lib = None
+
+c_f = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+c_i = C.c_int
+c_ll = C.c_longlong
+c_sz = C.c_size_t
+c_fl = C.c_float
+c_d = C.c_double
+
+# name -> (restype, argtypes). Mirrors include/r3m_hip.h one to one (tests/test_abi.py checks the header against it).
+SIGNATURES = {
+    "r3m_abi_version": (c_i, []),
+    "r3m_last_error": (C.c_char_p, []),
+    "r3m_profile_enable": (None, [c_i]),
+    "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
+    "r3m_resnet_create": (C.c_void_p, [c_i, c_i]),
+    "r3m_resnet_destroy": (None, [C.c_void_p]),
+    "r3m_resnet_out_dim": (c_i, [C.c_void_p]),
+    "r3m_resnet_num_params": (c_ll, [C.c_void_p]),
+    "r3m_resnet_num_buffers": (c_ll, [C.c_void_p]),
+    "r3m_resnet_arena_bytes": (c_ll, [C.c_void_p]),
+    "r3m_resnet_num_tensors": (c_i, [C.c_void_p]),
+    "r3m_resnet_tensor_info": (c_i, [C.c_void_p, c_i, C.c_char_p, c_i, C.POINTER(c_i), C.POINTER(c_ll), C.POINTER(c_i),
+                                     C.POINTER(c_i)]),
+    "r3m_resnet_stage_range": (c_i, [C.c_void_p, c_i, C.POINTER(c_ll), C.POINTER(c_ll)]),
+    "r3m_resnet_forward": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_i, c_f]),
+    "r3m_resnet_backward": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
+    "r3m_conv2d_stats_rows": (c_i, [c_i] * 7),
+    "r3m_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 8 + [c_f]),
+    "r3m_conv2d_dgrad_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "r3m_conv2d_dgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 8 + [c_f]),
+    "r3m_conv2d_wgrad_workspace_bytes": (c_sz, [c_i] * 8),
+    "r3m_conv2d_wgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 9 + [c_f]),
+    "r3m_stem_im2col": (c_i, [c_f, c_f, c_i, c_f]),
+    "r3m_bn_workspace_bytes": (c_sz, [c_ll, c_i]),
+    "r3m_bn_train_coeffs": (c_i, [c_f, c_i, c_ll, c_f, c_f, c_f, c_f, c_fl, c_fl, c_f, c_f, c_sz, c_i, c_f]),
+    "r3m_bn_eval_coeffs": (c_i, [c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_f]),
+    "r3m_bn_act_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f]),
+    "r3m_bn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_f]),
+    "r3m_maxpool_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_maxpool_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_avgpool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    "r3m_avgpool_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    "r3m_linear_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_loss_workspace_bytes": (c_sz, [c_i]),
+    "r3m_loss_tcn_lp": (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f]),
+    "r3m_loss_lang_infonce": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_fl, c_f]),
+    "r3m_loss_finalize": (c_i, [c_f, c_sz, c_i, c_i, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
+    "r3m_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_ll, c_d, c_d, c_d, c_d, c_ll, c_fl, c_f]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises HipLibraryMissing if the .so has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"r3m_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or r3m_amd/csrc/build.sh (hipcc --offload-arch=gfx950). There is no CPU / eager fallback.")
+    # torch (when already imported) has loaded its own libamdhip64.so.7; same SONAME -> one HIP runtime per process.
+    h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)  # AttributeError here means header/binding/library drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return h
+
+
+def last_error():
+    msg = lib().r3m_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"r3m_hip {what} failed (code {rc}): {last_error()}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()

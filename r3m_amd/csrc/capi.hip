@@ -27,6 +27,32 @@ int check_launch(const char* what) {
   return 0;
 }
 
+// ---- per-kernel-class event timing ----
+struct ProfEvent { hipEvent_t a, b; int kclass; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfEvent> g_prof_pool;
+static size_t g_prof_used = 0;
+static bool g_prof_open = false;
+
+void prof_begin(int kclass, double flops, hipStream_t s) {
+  if (!g_prof_on) return;
+  if (g_prof_used == g_prof_pool.size()) {
+    ProfEvent e;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+    g_prof_pool.push_back(e);
+  }
+  ProfEvent& e = g_prof_pool[g_prof_used];
+  e.kclass = kclass; e.flops = flops;
+  (void)hipEventRecord(e.a, s);
+  g_prof_open = true;
+}
+void prof_end(hipStream_t s) {
+  if (!g_prof_on || !g_prof_open) return;
+  (void)hipEventRecord(g_prof_pool[g_prof_used].b, s);
+  ++g_prof_used;
+  g_prof_open = false;
+}
+
 // engine.hip
 struct Plan;
 Plan* plan_create(int size, int F);
@@ -71,6 +97,20 @@ using namespace r3m;
 extern "C" {
 
 int r3m_abi_version(void) { return 1; }
+
+void r3m_profile_enable(int on) { g_prof_on = on != 0; if (!on) g_prof_used = 0; }
+int r3m_profile_collect(double* ms, long long* launches, double* flops) {
+  for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; flops[k] = 0.0; }
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    ProfEvent& e = g_prof_pool[i];
+    if (hipEventSynchronize(e.b) != hipSuccess) { set_last_error("profile_collect: event sync failed"); return 1; }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { set_last_error("profile_collect: elapsed failed"); return 1; }
+    ms[e.kclass] += t; launches[e.kclass] += 1; flops[e.kclass] += e.flops;
+  }
+  g_prof_used = 0;
+  return 0;
+}
 const char* r3m_last_error(void) { return g_err; }
 
 r3m_resnet_t r3m_resnet_create(int size, int frames) { return reinterpret_cast<r3m_resnet_t>(plan_create(size, frames)); }

@@ -106,6 +106,9 @@ int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, in
 int launch_avgpool_fwd(const float* X, float* H, int N, int HW, int C, hipStream_t s);
 int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStream_t s);
 
-// ---- launchers (adam.hip / loss.hip) declared in their own section of the C ABI ----
+// ---- optional per-kernel-class HIP-event timing (bench.py roofline; off by default, zero cost when off) ----
+enum { KC_GEMM_WIDE = 0, KC_GEMM_NARROW = 1, KC_WGRAD_WIDE = 2, KC_WGRAD_NARROW = 3, KC_COUNT = 4 };
+void prof_begin(int kclass, double flops, hipStream_t s);   // records the start event (no-op when disabled)
+void prof_end(hipStream_t s);                                // records the stop event
 
 }  // namespace r3m

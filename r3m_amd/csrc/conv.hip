@@ -246,13 +246,19 @@ int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.M > 0 && p.Nc > 0, "gather_gemm: empty problem M=%d Nc=%d", p.M, p.Nc);
   R3M_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0,
               "gather_gemm: operands must be 16-byte aligned");
+  // algorithmic FLOPs: the stem arrives as 160-wide patch rows of which 147 are real (7*7*3)
+  const double kdim = (double)p.ntaps * (p.Ci == 160 ? 147 : p.Ci);
+  const double flops = 2.0 * (double)p.M * (double)p.Nc * kdim;
   if (gg_wide(p.Nc)) {
     const int gm = ceil_div(p.M, 128), gn = ceil_div(p.Nc, 128);
+    prof_begin(KC_GEMM_WIDE, flops, s);
     hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2>), dim3(gm * gn), dim3(256), 0, s, p);
   } else {
     const int gm = ceil_div(p.M, 256), gn = ceil_div(p.Nc, 64);
+    prof_begin(KC_GEMM_NARROW, flops, s);
     hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1>), dim3(gm * gn), dim3(256), 0, s, p);
   }
+  prof_end(s);
   return check_launch("gather_gemm");
 }
 
@@ -390,15 +396,19 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
   p.rows_per_split = ((p.M + splitK - 1) / splitK + 31) / 32 * 32;
   R3M_REQUIRE(ceil_div(p.M, p.rows_per_split) == splitK, "wgrad: splitK=%d does not tile M=%d", splitK, p.M);
   const int T = p.KH * p.KW;
+  const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * (p.Ci == 160 ? 147 : p.Ci);
   if (wg_wide(p.Co, p.Ci)) {
     p.tilesN = ceil_div(p.Ci, 128);
     const int tiles = ceil_div(p.Co, 128) * p.tilesN * T;
+    prof_begin(KC_WGRAD_WIDE, flops, s);
     hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
+    prof_begin(KC_WGRAD_NARROW, flops, s);
     hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
   }
+  prof_end(s);
   return check_launch("wgrad");
 }
 

@@ -1,0 +1,292 @@
+"""ResNet-18/34/50 frame encoder on the HIP engine (libr3m_hip.so), behind an nn.Module that has the state-dict of
+torchvision.models.resnet{18,34,50} with fc = Identity — what the reference builds at
+/root/reference/r3m/models/models_r3m.py:44-52,62-63 and calls at :99.
+
+Design (MI355X-first, not a translation of torchvision's module graph):
+  * the network is ONE native plan in C++ (r3m_amd/csrc/engine.hip): forward and backward are single C calls that enqueue
+    the whole kernel sequence on the current HIP stream; Python owns only memory (torch allocator) and autograd glue;
+  * parameters are views into ONE flat fp32 buffer (torchvision order), gradients views into a second one: the fused Adam
+    step and the RCCL gradient all-reduce work on contiguous slices, no per-tensor loops, no bucket copies;
+  * conv weights are logical OIHW tensors with channels_last strides == the OHWI image the kernels read, so
+    load_state_dict()/state_dict() interchange with reference checkpoints needs no layout conversion.
+
+There is no CPU or eager fallback: forward() on a non-CUDA tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _Node(nn.Module):
+    """Anonymous container: exists only so parameter names nest like torchvision's (layer1.0.downsample.0.weight)."""
+
+
+def _tensor_table(size):
+    """[(name, kind, offset, shape)] from the native plan (torchvision state-dict order)."""
+    L = _lib.lib()
+    h = L.r3m_resnet_create(size, 1)
+    if not h:
+        raise ValueError(_lib.last_error())
+    try:
+        out = []
+        name = C.create_string_buffer(128)
+        kind, ndim = C.c_int(), C.c_int()
+        off = C.c_longlong()
+        shape = (C.c_int * 4)()
+        for i in range(L.r3m_resnet_num_tensors(h)):
+            _lib.check(L.r3m_resnet_tensor_info(h, i, name, 128, C.byref(kind), C.byref(off), C.byref(ndim), shape), "tensor_info")
+            out.append((name.value.decode(), kind.value, off.value, tuple(shape[k] for k in range(ndim.value))))
+        return out, L.r3m_resnet_num_params(h), L.r3m_resnet_num_buffers(h), L.r3m_resnet_out_dim(h)
+    finally:
+        L.r3m_resnet_destroy(h)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """h = encoder(x). Backward writes parameter gradients straight into the module's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module, training):
+        h = module._run_forward(x, training)
+        ctx.module = module
+        ctx.generation = module._generation
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        ctx.module._run_backward(dh.contiguous(), ctx.generation)
+        return None, None, None, None
+
+
+class HipResNet(nn.Module):
+    def __init__(self, size):
+        super().__init__()
+        table, n_params, n_buffers, out_dim = _tensor_table(size)
+        self.size = size
+        self.outdim = out_dim
+        self._n_params = n_params
+        self._n_buffers = n_buffers
+        self._table = table
+        self._slots = []        # (tensor, kind, offset, shape) in table order, for re-flattening
+        flat_p = torch.zeros(n_params, dtype=torch.float32)
+        flat_b = torch.zeros(n_buffers, dtype=torch.float32)
+        n_bn = sum(1 for t in table if t[1] == 1)
+        flat_nbt = torch.zeros(n_bn, dtype=torch.int64)
+        bn_i = 0
+        for name, kind, off, shape in table:
+            parent, leaf = self._resolve(name)
+            n = int(math.prod(shape))
+            if kind == 0:
+                O, I, kh, kw = shape
+                t = nn.Parameter(flat_p[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2))  # logical OIHW, physical OHWI
+                parent.register_parameter(leaf, t)
+            elif kind in (1, 2):
+                t = nn.Parameter(flat_p[off:off + n].view(shape))
+                parent.register_parameter(leaf, t)
+            else:
+                t = flat_b[off:off + n].view(shape)
+                parent.register_buffer(leaf, t)
+                if kind == 4:
+                    parent.register_buffer("num_batches_tracked", flat_nbt[bn_i])
+                    bn_i += 1
+        self.fc = nn.Identity()   # models_r3m.py:62
+        self._flat_p, self._flat_b, self._flat_nbt = flat_p, flat_b, flat_nbt
+        self._flat_g = None
+        self._plans = {}          # F -> native handle
+        self._arena = None
+        self._generation = 0
+        self._live_F = None
+        self._grad_fresh = True
+        self._stage_hook = None   # callable(stage, offset, count) after each backward stage (data-parallel wrapper)
+        self.reset_parameters()
+
+    # ---- structure -------------------------------------------------------------------------------------------
+    def _resolve(self, dotted):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Node())
+            mod = mod._modules[p]
+        return mod, parts[-1]
+
+    def _named_slots(self):
+        """(name, kind, offset, shape, tensor) following the native table."""
+        sd_p = dict(self.named_parameters())
+        sd_b = dict(self.named_buffers())
+        for name, kind, off, shape in self._table:
+            yield name, kind, off, shape, (sd_p[name] if kind <= 2 else sd_b[name])
+
+    def reset_parameters(self):
+        """torchvision ResNet init: kaiming_normal_(fan_out, relu) on convs, BN weight 1 / bias 0.
+        Draws from the global torch RNG in state-dict order, like torchvision's `for m in self.modules()` loop."""
+        with torch.no_grad():
+            for name, kind, off, shape, t in self._named_slots():
+                if kind == 0:
+                    w = torch.empty(shape, dtype=torch.float32)
+                    nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+                    t.copy_(w)
+                elif kind == 1 or kind == 4:
+                    t.fill_(1.0)
+                else:
+                    t.zero_()
+            self._flat_nbt.zero_()
+
+    # ---- flat storage ----------------------------------------------------------------------------------------
+    def _is_flat(self):
+        base = self._flat_p.data_ptr()
+        dev = self._flat_p.device
+        for name, kind, off, shape, t in self._named_slots():
+            if kind <= 2 and (t.device != dev or t.data_ptr() != base + off * 4):
+                return False
+            if kind > 2 and (t.device != self._flat_b.device or t.data_ptr() != self._flat_b.data_ptr() + off * 4):
+                return False
+        return True
+
+    def _reflatten(self):
+        """Re-establish 'every tensor is a view of the flat buffers' after .to()/.cuda()/deepcopy/load with assign."""
+        slots = list(self._named_slots())
+        dev = slots[0][4].device
+        for _, _, _, _, t in slots:
+            if t.dtype != torch.float32:
+                raise TypeError("r3m_amd.HipResNet keeps fp32 master parameters; dtype conversion is not supported")
+        flat_p = torch.zeros(self._n_params, dtype=torch.float32, device=dev)
+        flat_b = torch.zeros(self._n_buffers, dtype=torch.float32, device=dev)
+        flat_nbt = torch.zeros_like(self._flat_nbt, device=dev)
+        bn_i = 0
+        with torch.no_grad():
+            for name, kind, off, shape, t in slots:
+                n = int(math.prod(shape))
+                if kind == 0:
+                    O, I, kh, kw = shape
+                    v = flat_p[off:off + n].view(O, kh, kw, I).permute(0, 3, 1, 2)
+                elif kind in (1, 2):
+                    v = flat_p[off:off + n].view(shape)
+                else:
+                    v = flat_b[off:off + n].view(shape)
+                v.copy_(t)
+                if kind <= 2:
+                    t.data = v
+                    t.grad = None
+                else:
+                    parent, leaf = self._resolve(name)
+                    parent._buffers[leaf] = v
+                    if kind == 4:
+                        old = parent._buffers["num_batches_tracked"]
+                        flat_nbt[bn_i] = old.to(dev)
+                        parent._buffers["num_batches_tracked"] = flat_nbt[bn_i]
+                        bn_i += 1
+        self._flat_p, self._flat_b, self._flat_nbt = flat_p, flat_b, flat_nbt
+        self._flat_g = None
+        self._arena = None
+        self._grad_fresh = True
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._reflatten()
+        return self
+
+    def flat_params(self):
+        self._ensure()
+        return self._flat_p
+
+    def flat_grads(self):
+        self._ensure()
+        if self._flat_g is None:
+            self._flat_g = torch.zeros_like(self._flat_p)
+            for name, kind, off, shape, t in self._named_slots():
+                if kind == 0:
+                    O, I, kh, kw = shape
+                    t.grad = self._flat_g[off:off + t.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2)
+                elif kind <= 2:
+                    t.grad = self._flat_g[off:off + t.numel()].view(shape)
+        return self._flat_g
+
+    def _ensure(self):
+        if not self._is_flat():
+            self._reflatten()
+
+    def mark_grads_stale(self):
+        """Called by the optimizer's zero_grad(): the next backward overwrites instead of accumulating."""
+        self._grad_fresh = True
+
+    def stage_range(self, stage):
+        L = _lib.lib()
+        h = self._plan(1)
+        off, cnt = C.c_longlong(), C.c_longlong()
+        _lib.check(L.r3m_resnet_stage_range(h, stage, C.byref(off), C.byref(cnt)), "stage_range")
+        return off.value, cnt.value
+
+    # ---- execution -------------------------------------------------------------------------------------------
+    def _plan(self, F):
+        h = self._plans.get(F)
+        if h is None:
+            h = _lib.lib().r3m_resnet_create(self.size, F)
+            if not h:
+                raise RuntimeError(_lib.last_error())
+            self._plans[F] = h
+        return h
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for h in self._plans.values():
+                L.r3m_resnet_destroy(h)
+        except Exception:
+            pass
+
+    def _run_forward(self, x, training):
+        L = _lib.lib()
+        F = x.shape[0]
+        h = self._plan(F)
+        need = L.r3m_resnet_arena_bytes(h)
+        if self._arena is None or self._arena.numel() < need or self._arena.device != x.device:
+            self._arena = None  # release first: the arena is the dominant HBM allocation
+            self._arena = torch.empty(need, dtype=torch.uint8, device=x.device)
+        out = torch.empty((F, self.outdim), dtype=torch.float32, device=x.device)
+        _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
+                                        out.data_ptr(), 1 if training else 0, _lib.stream_ptr()), "resnet_forward")
+        if training:
+            self._flat_nbt += 1
+        self._generation += 1
+        self._live_F = F
+        return out
+
+    def _run_backward(self, dh, generation):
+        if generation != self._generation:
+            raise RuntimeError("r3m_amd: the encoder ran another forward before this backward; its saved activations "
+                               "(one HBM arena per module) were overwritten")
+        L = _lib.lib()
+        h = self._plan(self._live_F)
+        g = self.flat_grads()
+        accumulate = 0 if self._grad_fresh else 1
+        for stage in range(4):
+            _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), self._arena.data_ptr(), stage,
+                                             stage + 1, accumulate, _lib.stream_ptr()), "resnet_backward")
+            if self._stage_hook is not None:
+                off, cnt = self.stage_range(stage)
+                self._stage_hook(stage, off, cnt)
+        self._grad_fresh = False
+
+    def forward(self, x):
+        """x: [F,3,224,224] float32 CUDA tensor with values in 0..255 (the /255 and Normalize of R3M.forward are fused into
+        the stem kernel). Returns [F, outdim]."""
+        if not x.is_cuda:
+            raise RuntimeError("r3m_amd: the encoder runs on MI355X through libr3m_hip.so only; got a CPU tensor "
+                               "(no CPU / eager fallback exists — the CPU oracle lives under oracle/ for tests)")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+            raise ValueError(f"expected [F,3,224,224], got {tuple(x.shape)}")
+        self._ensure()
+        if self._flat_p.device != x.device:
+            raise RuntimeError(f"encoder parameters on {self._flat_p.device}, input on {x.device}")
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            anchor = next(self.parameters())
+            return _EncoderFn.apply(x, anchor, self, self.training)
+        return self._run_forward(x, self.training)

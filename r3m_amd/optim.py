@@ -1,0 +1,67 @@
+"""Fused Adam over flat parameter buffers (one HIP kernel per flat buffer) — the `encoder_opt` of R3M.
+
+Replaces torch.optim.Adam(params, lr=lr) built at /root/reference/r3m/models/models_r3m.py:76 and stepped at
+/root/reference/r3m/trainer.py:156-158 (defaults: betas (0.9, 0.999), eps 1e-8, weight_decay 0, amsgrad False).
+"""
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """`owners` are modules exposing flat_params() / flat_grads() / mark_grads_stale() (HipResNet, LanguageReward)."""
+
+    def __init__(self, owners, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.owners = list(owners)
+        params = [p for o in self.owners for p in o.parameters()]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._step = 0
+        self._m = [None] * len(self.owners)
+        self._v = [None] * len(self.owners)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=True):
+        # Gradients live in persistent flat buffers; "zeroing" = the next backward overwrites them (no memset pass).
+        for o in self.owners:
+            o.mark_grads_stale()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FusedAdam.step(closure) is not supported")
+        g0 = self.param_groups[0]
+        lr, (b1, b2), eps = g0["lr"], g0["betas"], g0["eps"]
+        self._step += 1
+        L = _lib.lib()
+        for i, o in enumerate(self.owners):
+            p = o.flat_params()
+            if not p.is_cuda:
+                raise RuntimeError("r3m_amd.FusedAdam: parameters must live on the GPU (HIP kernel, no CPU fallback)")
+            if not getattr(o, "has_grads", lambda: True)():
+                continue
+            g = o.flat_grads()
+            if self._m[i] is None or self._m[i].device != p.device or self._m[i].numel() != p.numel():
+                self._m[i] = torch.zeros_like(p)
+                self._v[i] = torch.zeros_like(p)
+            n = p.numel()
+            pad = (-n) % 4
+            assert pad == 0, "flat buffers are padded to multiples of 4 floats"
+            _lib.check(L.r3m_adam_step(p.data_ptr(), g.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr(), n, float(lr),
+                                       float(b1), float(b2), float(eps), self._step, float(self.grad_scale), _lib.stream_ptr()),
+                       "adam_step")
+
+    # state: enough to resume (the reference never saved optimizer state, train_representation.py:123-130)
+    def state_dict(self):
+        return {"step": self._step, "exp_avg": [None if m is None else m.cpu() for m in self._m],
+                "exp_avg_sq": [None if v is None else v.cpu() for v in self._v], "param_groups": [
+                    {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["step"])
+        for i, o in enumerate(self.owners):
+            if sd["exp_avg"][i] is not None:
+                dev = o.flat_params().device
+                self._m[i] = sd["exp_avg"][i].to(dev)
+                self._v[i] = sd["exp_avg_sq"][i].to(dev)
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)

@@ -1,0 +1,107 @@
+"""Data parallelism for the R3M step: one process per GPU, RCCL over xGMI through torch.distributed (backend "nccl" is
+RCCL on ROCm), gradient all-reduce overlapped with the remaining backward.
+
+The reference uses single-process torch.nn.DataParallel (/root/reference/r3m/train_representation.py:27-31, r3m/__init__.py:72):
+per-step replicate + scatter + gather + reduce-to-GPU-0, loss and Adam on GPU 0 only. Here every rank owns a full replica
+and a shard of the clips; the only exchange is the gradient mean:
+
+  * gradients already sit in ONE flat buffer in layer order, so a "bucket" is a slice — no flatten/unflatten copies;
+  * the encoder backward is issued in 4 stages (layer4, layer3, layer2, layer1+stem); after each, the finished slice
+    (60 MB, 28 MB, 5 MB, 1 MB for ResNet-50) goes out as an async all-reduce that runs while the next stage computes.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages keep every link busy, per-tensor ones don't;
+  * BatchNorm statistics stay per-rank (as the reference's DataParallel does per replica chunk); negatives are drawn within
+    the rank's shard.
+
+Both wrappers expose `.module` like DataParallel, which Trainer.update and the snapshot code rely on
+(trainer.py:58-59,72,127,156-158; train_representation.py:126).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradSync:
+    """Mean-all-reduce of slices of flat gradient buffers; device-agnostic (RCCL on GPUs, gloo on CPU in tests)."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._pending = []   # (work, slice, needs_div)
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._avg = backend == "nccl"   # RCCL reduces with AVG natively; gloo has SUM only
+
+    def reduce_slice(self, flat, offset, count):
+        if self.world == 1 or count == 0:
+            return
+        sl = flat[offset:offset + count]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
+        self._pending.append((work, sl, not self._avg))
+
+    def finish(self):
+        for work, sl, needs_div in self._pending:
+            work.wait()           # on GPUs: the current stream waits for RCCL's stream; no host block
+            if needs_div:
+                sl.div_(self.world)
+        self._pending.clear()
+
+    def broadcast(self, tensor, src=0):
+        if self.world > 1:
+            dist.broadcast(tensor, src=src, group=self.group)
+
+
+class SingleDevice(nn.Module):
+    """world_size == 1 stand-in for the reference's DataParallel wrapper: only provides `.module`."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def finish_gradient_sync(self):
+        pass
+
+
+class DistributedR3M(nn.Module):
+    """One replica per rank. Construct AFTER torch.distributed.init_process_group and after moving `module` to its GPU."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        self.module = module
+        self.sync = GradSync(process_group)
+        # identical replicas: rank 0's parameters and BatchNorm buffers win
+        for owner in self._owners():
+            self.sync.broadcast(owner.flat_params())
+        conv = module.convnet
+        self.sync.broadcast(conv._flat_b)
+        conv._stage_hook = self._on_stage
+
+    def _owners(self):
+        return list(self.module.encoder_opt.owners)
+
+    def _on_stage(self, stage, offset, count):
+        self.sync.reduce_slice(self.module.convnet.flat_grads(), offset, count)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def finish_gradient_sync(self):
+        """Call after backward, before the optimizer step: reduces the (small) language-head gradients and waits for the
+        encoder slices launched during backward."""
+        for owner in self._owners():
+            if owner is self.module.convnet:
+                continue
+            if getattr(owner, "has_grads", lambda: True)():
+                g = owner.flat_grads()
+                self.sync.reduce_slice(g, 0, g.numel())
+        self.sync.finish()
+
+
+def make_network_wrapper(model):
+    """What `make_network` (train_representation.py:27-31) returns here: DistributedR3M when a process group exists and
+    world_size > 1, else the trivial wrapper."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return DistributedR3M(model)
+    return SingleDevice(model)

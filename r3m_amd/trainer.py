@@ -1,0 +1,82 @@
+"""Trainer.update — one pre-training (or eval) step; same signature, metric keys and RNG consumption order as the reference
+(/root/reference/r3m/trainer.py:21-162), restructured for the GPU:
+
+  * the 5B frames go through the HIP encoder engine in one call (trainer.py:39-41);
+  * LP norms + TCN InfoNCE + language InfoNCE are the fused loss kernels of csrc/loss.hip, forward and backward together
+    (trainer.py:52-59, 64-118, 122-150) — the permutations are still drawn with torch.randperm on the CPU generator in the
+    reference's order (language: (a,b,c) x 3 at :86-92, then TCN: (es0, es2) x 3 at :136-137), uploaded once;
+  * the 15 reward-head evaluations are one batched [15B, 2D+768] GEMM chain (models_language.LanguageReward.batched);
+    the frozen sentence features are computed once per step instead of 15 times (trainer.py:72-92 -> models_r3m.py:78-81);
+  * all metrics come back in ONE device->host copy instead of ~10 .item() syncs.
+"""
+import time
+
+import torch
+
+from . import ops
+
+epsilon = 1e-8
+
+
+class Trainer:
+    def __init__(self, eval_freq):
+        self.eval_freq = eval_freq
+
+    def update(self, model, batch, step, eval=False):
+        t0 = time.time()
+        metrics = dict()
+        if eval:
+            model.eval()
+        else:
+            model.train()
+        t1 = time.time()
+        b_im, b_lang = batch
+        t2 = time.time()
+        core = model.module
+
+        bs = b_im.shape[0]
+        b_im_r = b_im.reshape(bs * 5, 3, 224, 224)
+        alles = model(b_im_r)
+        alle = alles.reshape(bs, 5, -1)
+        t3 = time.time()
+
+        # ---- permutations, in the reference's order of torch.randperm draws ----
+        scores = mask = None
+        lang_perm = None
+        if core.langweight > 0:
+            lang_perm = torch.stack([torch.randperm(bs) for _ in range(3 * core.num_negatives)])  # (a,b,c) x num_neg
+        tcn_perm = None
+        if core.tcnweight > 0:
+            tcn_perm = torch.stack([torch.randperm(bs) for _ in range(2 * core.num_negatives)]).to(torch.int32)
+            tcn_perm = tcn_perm.to(alle.device, non_blocking=True)
+
+        if core.langweight > 0:
+            scores = core.lang_rew.batched_scores(alle, core.lang_enc(b_lang), lang_perm.to(alle.device))
+            mask = torch.tensor([1.0 * (b != "") for b in b_lang], dtype=torch.float32, device=alle.device)
+        t5 = time.time()
+
+        full_loss, m = ops.r3m_loss(alle, tcn_perm, core.l2weight, core.l1weight, core.tcnweight, l2dist=core.l2dist,
+                                    scores=scores, mask=mask, langweight=core.langweight)
+        t6 = time.time()
+        if not eval:
+            core.encoder_opt.zero_grad()
+            full_loss.backward()
+            sync = getattr(model, "finish_gradient_sync", None)
+            if sync is not None:
+                sync()
+            core.encoder_opt.step()
+
+        mh = m.tolist()   # the step's single device->host sync
+        for k in ("l2loss", "l1loss", "l0loss"):
+            metrics[k] = mh[ops.METRIC_SLOTS[k]]
+        if core.langweight > 0:
+            for k in ("rewloss", "rewacc1", "rewacc2", "rewacc3"):
+                metrics[k] = mh[ops.METRIC_SLOTS[k]]
+        if core.tcnweight > 0:
+            for k in ("tcnloss", "aligned"):
+                metrics[k] = mh[ops.METRIC_SLOTS[k]]
+        metrics["full_loss"] = mh[ops.METRIC_SLOTS["full_loss"]]
+        t7 = time.time()
+        st = (f"Load time {t1-t0}, Batch time {t2-t1}, Encode time {t3-t2}, Lang time {t5-t3}, "
+              f"Loss time {t6-t5}, Backprop time {t7-t6}")
+        return metrics, st

@@ -1,0 +1,196 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own code (imported by path, oracle/by_path.py) on CPU fp32.
+Run in the authoring container only (needs /root/reference):   python tests/golden/make_golden.py
+Inputs and weights come from oracle/detgen.py (hash generator) so they are NOT stored — only the expected outputs are.
+
+  G1/G2  encoder_r{18,34,50}.npz : reference R3M.forward on 8 frames, train and eval mode; running stats; gradients of
+                                   L = sum(h * cw) (full conv1/bn1 grads + L2 norm of every parameter gradient)
+  G3     loss_{l2,cos}.npz       : reference Trainer.update on given embeddings (fake encoder), TCN + LP + language
+                                   InfoNCE with the reference LanguageReward: metrics, d full_loss/d alle, scores, head grads
+  G5     step_r18.npz            : two full reference Trainer.update steps (R3M + Adam), B=2 clips
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import by_path, detgen  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def set_state(model_convnet, tag="w"):
+    shapes = [(k, tuple(v.shape)) for k, v in model_convnet.state_dict().items()]
+    sd = detgen.resnet_state_dict(shapes, tag)
+    model_convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+
+
+def last_bn_name(size):
+    return "layer4.2.bn3" if size == 50 else ("layer4.1.bn2" if size == 18 else "layer4.2.bn2")
+
+
+def encoder_golden(size, F=8):
+    r3m, _, _ = by_path.load_reference()
+    m = r3m.R3M("cpu", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0)
+    set_state(m.convnet)
+    x = torch.from_numpy(detgen.frames(f"frames{F}", (F, 3, 224, 224)))
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        out["h_eval"] = m(x).numpy()
+    m.train()
+    h = m(x)
+    out["h_train"] = h.detach().numpy()
+    sd = m.convnet.state_dict()
+    lb = last_bn_name(size)
+    for k in ("bn1.running_mean", "bn1.running_var", lb + ".running_mean", lb + ".running_var"):
+        out["post_" + k] = sd[k].numpy().copy()
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5))
+    (h * cw).sum().backward()
+    names, norms = [], []
+    for k, p in m.convnet.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    P = dict(m.convnet.named_parameters())
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",
+              "layer2.0.downsample.0.weight"):
+        out["grad_" + k] = P[k].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"encoder_r{size}.npz"), **out)
+    print("encoder", size, out["h_train"].shape, float(np.abs(out["h_train"]).max()))
+
+
+class _FakeCore(torch.nn.Module):
+    """Stands where `model.module` does in the reference Trainer: loss weights, sim, get_reward with fixed text features."""
+
+    def __init__(self, ref_r3m_mod, ref_lang_mod, D, l2dist, langweight, feats):
+        super().__init__()
+        self.l2weight, self.l1weight, self.tcnweight, self.langweight = 1e-5, 1e-5, 1.0, langweight
+        self.num_negatives = 3
+        self.l2dist = l2dist
+        self.cs = torch.nn.CosineSimilarity(1)
+        self.lang_rew = ref_lang_mod.LanguageReward(None, D, 1024, 768)
+        self.feats = feats
+        self._sim = ref_r3m_mod.R3M.sim
+
+    def sim(self, a, b):
+        return self._sim(self, a, b)     # the reference's own R3M.sim body
+
+    def get_reward(self, e0, es, sentences):
+        return self.lang_rew(e0, es, self.feats)
+
+    class _Opt:
+        def zero_grad(self): pass
+        def step(self): pass
+    encoder_opt = _Opt()
+
+
+class _FakeModel(torch.nn.Module):
+    def __init__(self, core, alles):
+        super().__init__()
+        self.module = core
+        self.alles = alles
+
+    def forward(self, x):
+        return self.alles
+
+
+def make_alle(B, D, tag):
+    u = detgen.uniform(tag, (B, 5, D), 0.0, 1.0)
+    a = np.maximum(u - 0.3, 0.0) * 2.0      # ~30 % exact zeros, like avg-pooled ReLU features
+    a[3, 4] = a[3, 3]                        # es2 == es1 for one clip -> s12 == 0 exactly (data_loaders.py:77-79 allows it)
+    return a.astype(np.float32)
+
+
+def loss_golden(l2dist, B=8, D=512):
+    r3m, lang, trainer = by_path.load_reference()
+    feats = torch.from_numpy(detgen.uniform("langfeat", (B, 768), -0.6, 0.6))
+    core = _FakeCore(r3m, lang, D, l2dist, 1.0, feats)
+    shapes = [(k, tuple(v.shape)) for k, v in core.lang_rew.state_dict().items()]
+    sd = {}
+    for k, shp in shapes:
+        fan_in = shp[1] if len(shp) == 2 else shapes[[s[0] for s in shapes].index(k.replace("bias", "weight"))][1][1]
+        a = 1.0 / np.sqrt(fan_in)
+        sd[k] = torch.from_numpy(detgen.uniform("lr" + k, shp, -a, a))
+    core.lang_rew.load_state_dict(sd)
+    alles = torch.from_numpy(make_alle(B, D, "alle").reshape(B * 5, D)).requires_grad_(True)
+    model = _FakeModel(core, alles)
+    b_lang = ["open the drawer"] * B
+    b_lang[5] = ""                           # masked clip (trainer.py:107-109)
+    seed = 1234
+    torch.manual_seed(seed)
+    perms = torch.stack([torch.randperm(B) for _ in range(15)])   # the draws Trainer.update is about to make
+    torch.manual_seed(seed)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self                # trainer.py:108 hard-codes .cuda()
+    try:
+        metrics, _ = trainer.Trainer(1).update(model, (torch.zeros(B, 5, 3, 224, 224), b_lang), 0)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out = {"perms": perms.numpy(), "dalle": alles.grad.numpy().reshape(B, 5, D).copy(),
+           "metric_names": np.array(list(metrics.keys())), "metric_values": np.array(list(metrics.values()), dtype=np.float64)}
+    for k, p in core.lang_rew.named_parameters():
+        out["gradnorm_" + k] = np.array(float(p.grad.double().norm()))
+    out["grad_pred.8.weight"] = core.lang_rew.pred[8].weight.grad.numpy().copy()
+    out["grad_pred.0.bias"] = core.lang_rew.pred[0].bias.grad.numpy().copy()
+    # scores of the 15 reward evaluations in call order, recomputed with the same perms (no grad)
+    with torch.no_grad():
+        alle = alles.detach().reshape(B, 5, D)
+        e0, eg, es0, es1, es2 = [alle[:, i] for i in range(5)]
+        G = lambda a, b: core.lang_rew(a, b, feats)[0]
+        sc = [G(e0, eg), G(e0, es1), G(e0, es2), G(e0, e0), G(e0, es0), G(e0, es1)]
+        for k in range(3):
+            for j, other in enumerate((eg, es1, es2)):
+                p = perms[3 * k + j]
+                sc.append(G(e0[p], other[p]))
+        out["scores"] = torch.stack(sc).numpy()
+    np.savez_compressed(os.path.join(OUT, f"loss_{'l2' if l2dist else 'cos'}.npz"), **out)
+    print("loss", "l2" if l2dist else "cos", dict(zip(metrics.keys(), [round(v, 6) for v in metrics.values()])))
+
+
+def step_golden(size=18, B=2, nsteps=2):
+    r3m, _, trainer = by_path.load_reference()
+    m = r3m.R3M("cpu", 1e-4, 1024, size=size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    set_state(m.convnet)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, mod):
+            super().__init__()
+            self.module = mod
+
+        def forward(self, x):
+            return self.module(x)
+
+    model = Wrap(m)
+    frames = torch.from_numpy(detgen.frames("stepframes", (B, 5, 3, 224, 224)))
+    out = {}
+    seed = 77
+    torch.manual_seed(seed)
+    perms = [torch.stack([torch.randperm(B) for _ in range(6)]) for _ in range(nsteps)]
+    torch.manual_seed(seed)
+    T = trainer.Trainer(1)
+    for s in range(nsteps):
+        metrics, _ = T.update(model, (frames, [""] * B), s)
+        out[f"metric_values_{s}"] = np.array(list(metrics.values()), dtype=np.float64)
+        out["metric_names"] = np.array(list(metrics.keys()))
+        out[f"perms_{s}"] = perms[s].numpy()
+    sd = m.convnet.state_dict()
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "layer4.1.bn2.weight",
+              "layer4.1.conv2.weight", "layer1.0.conv1.weight"):
+        out["post_" + k] = sd[k].numpy().copy() if sd[k].numel() < 50000 else sd[k].numpy().reshape(-1)[:50000].copy()
+    out["nbt"] = sd["bn1.num_batches_tracked"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"step_r{size}.npz"), **out)
+    print("step", [out[f"metric_values_{s}"] for s in range(nsteps)])
+
+
+if __name__ == "__main__":
+    assert by_path.available(), "/root/reference is required to (re)generate goldens"
+    for size in (18, 34, 50):
+        encoder_golden(size)
+    loss_golden(True)
+    loss_golden(False)
+    step_golden()

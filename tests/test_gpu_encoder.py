@@ -1,0 +1,162 @@
+"""-m gpu: the HIP encoder engine / loss / full step against the committed golden vectors (made by the reference's own code,
+tests/golden/make_golden.py) and against the CPU oracle at other sizes. Gate: encoder outputs max|d|/max|ref| <= 1e-4
+(BASELINE.json north_star: 'within 1e-4 rel-err of CPU reference'), fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load_state(convnet, tag="w"):
+    from oracle import detgen
+    shapes = [(k, tuple(v.shape)) for k, v in convnet.state_dict().items()]
+    sd = detgen.resnet_state_dict(shapes, tag)
+    convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+
+
+def _last_bn(size):
+    return "layer4.2.bn3" if size == 50 else ("layer4.1.bn2" if size == 18 else "layer4.2.bn2")
+
+
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_encoder_matches_reference_golden(hip, golden_dir, size):
+    from oracle import detgen
+    from r3m_amd import R3M
+    g = np.load(os.path.join(golden_dir, f"encoder_r{size}.npz"))
+    m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0)
+    _load_state(m.convnet)
+    m = m.to(DEV)
+    x = torch.from_numpy(detgen.frames("frames8", (8, 3, 224, 224))).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        h_eval = m(x).cpu().numpy()
+    e_max, e_l2 = rel_err(h_eval, g["h_eval"])
+    print(f"r{size} eval: max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+    assert e_max <= 1e-4
+    m.train()
+    h = m(x)
+    e_max, e_l2 = rel_err(h.detach().cpu().numpy(), g["h_train"])
+    print(f"r{size} train: max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+    assert e_max <= 1e-4
+    sd = m.convnet.state_dict()
+    lb = _last_bn(size)
+    for k in ("bn1.running_mean", "bn1.running_var", lb + ".running_mean", lb + ".running_var"):
+        assert rel_err(sd[k].cpu().numpy(), g["post_" + k])[0] < 1e-4, k
+    assert int(sd["bn1.num_batches_tracked"]) == 1
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).to(DEV)
+    (h * cw).sum().backward()
+    P = dict(m.convnet.named_parameters())
+    worst = 0.0
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        got = float(P[str(name)].grad.double().norm())
+        worst = max(worst, abs(got - ref) / max(ref, 1e-12))
+    print(f"r{size} grad-norm worst rel {worst:.3e}")
+    # Gradient tolerance: fp32 round-off is amplified through 18-50 train-mode BatchNorm backward passes. Measured noise
+    # floor: the reference's OWN PyTorch-CPU fp32 gradients sit 5e-3 (l2-rel, conv1.weight) / 1e-3 (norms) away from an
+    # fp64 evaluation of the same graph (tests/golden/encoder_r18_fp64.npz), so fp32-vs-fp32 is gated at 2e-2 / 1e-2 and
+    # ResNet-18 is additionally gated against fp64 relative to that floor below.
+    assert worst < 1e-2
+    keys = ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",
+            "layer2.0.downsample.0.weight")
+    for k in keys:
+        e_max, e_l2 = rel_err(P[k].grad.cpu().numpy(), g["grad_" + k])
+        print(f"r{size} grad {k}: max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+        assert e_l2 < 2e-2, k
+    if size == 18:
+        g64 = np.load(os.path.join(golden_dir, "encoder_r18_fp64.npz"))
+        for k in keys:
+            hip_err = rel_err(P[k].grad.cpu().numpy(), g64["grad_" + k])[1]
+            cpu_err = rel_err(g["grad_" + k], g64["grad_" + k])[1]
+            print(f"r18 grad {k}: vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}")
+            assert hip_err <= 3.0 * cpu_err + 1e-5, k
+
+
+@pytest.mark.parametrize("l2dist", [True, False])
+def test_tcn_lp_loss_matches_reference_golden(hip, golden_dir, l2dist):
+    """G3 (TCN + LP part): same embeddings and permutations as the reference's Trainer.update run."""
+    from r3m_amd import ops
+    g = np.load(os.path.join(golden_dir, f"loss_{'l2' if l2dist else 'cos'}.npz"))
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import make_alle
+    B, D = 8, 512
+    alle = torch.from_numpy(make_alle(B, D, "alle")).to(DEV).requires_grad_(True)
+    perms = torch.from_numpy(g["perms"])
+    tcn_perm = perms[9:15].to(torch.int32).to(DEV)
+    full, m = ops.r3m_loss(alle, tcn_perm, 1e-5, 1e-5, 1.0, l2dist=l2dist)
+    names = [str(n) for n in g["metric_names"]]
+    ref = dict(zip(names, g["metric_values"]))
+    got = m.cpu().numpy()
+    for k in ("l2loss", "l1loss", "l0loss", "tcnloss", "aligned"):
+        assert abs(got[ops.METRIC_SLOTS[k]] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, got[ops.METRIC_SLOTS[k]], ref[k])
+    # the golden full_loss / dalle include the language term; its part is checked in test_gpu_lang.py. Here: oracle on CPU.
+    from oracle import r3m_ref
+    mref = r3m_ref.R3MRef(size=18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0, l2dist=l2dist)
+    a2 = alle.detach().cpu().requires_grad_(True)
+    fl, met, _ = r3m_ref.r3m_loss_ref(mref, a2, tcn_perm=perms[9:15])
+    fl.backward()
+    assert abs(float(full) - met["full_loss"]) <= 1e-5 * abs(met["full_loss"])
+    full.backward()
+    e_max, e_l2 = rel_err(alle.grad.cpu().numpy(), a2.grad.numpy())
+    print(f"loss grad l2dist={l2dist}: max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+    assert e_max < 1e-4
+
+
+def test_full_step_matches_reference_golden(hip, golden_dir):
+    """G5: two Trainer.update steps (encoder + loss + backward + Adam) on ResNet-18, B = 2 clips."""
+    from oracle import detgen
+    from r3m_amd import R3M
+    from r3m_amd.parallel import SingleDevice
+    from r3m_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, "step_r18.npz"))
+    m = R3M("cuda", 1e-4, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    _load_state(m.convnet)
+    model = SingleDevice(m).to(DEV)
+    frames = torch.from_numpy(detgen.frames("stepframes", (2, 5, 3, 224, 224))).to(DEV)
+    torch.manual_seed(77)
+    T = Trainer(1)
+    names = [str(n) for n in g["metric_names"]]
+    for s in range(2):
+        metrics, _ = T.update(model, (frames, [""] * 2), s)
+        assert list(metrics.keys()) == names
+        ref = dict(zip(names, g[f"metric_values_{s}"]))
+        # step 0 sees identical weights: tight. Step 1 follows an Adam update whose first step moves every weight by
+        # +-lr according to the SIGN of its gradient; fp32-noise-level gradients flip sign between any two fp32
+        # implementations, so the second step's loss agrees to ~1e-3 only (chaotic, not a kernel property).
+        tol = 2e-4 if s == 0 else 5e-3
+        for k in names:
+            assert abs(metrics[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (s, k, metrics[k], ref[k])
+    sd = m.convnet.state_dict()
+    lr = 1e-4
+    for k in ("bn1.weight", "bn1.bias", "layer4.1.bn2.weight", "conv1.weight"):
+        got = sd[k].cpu().numpy().reshape(-1)[:50000]
+        ref = g["post_" + k].reshape(-1)
+        d = np.abs(got - ref)
+        flipped = float((d > 0.2 * lr).mean())
+        print("post-step", k, "max abs diff", d.max(), "fraction beyond 0.2*lr", flipped)
+        assert d.max() <= 4 * lr * 1.05 and flipped < 0.05, k     # two steps of at most 2*lr each, for few elements
+    for k in ("bn1.running_mean", "bn1.running_var"):
+        assert rel_err(sd[k].cpu().numpy(), g["post_" + k])[0] < 1e-4, k
+    assert int(sd["bn1.num_batches_tracked"]) == 2
+
+
+def test_encoder_large_batch_properties(hip):
+    """Full-size-ish properties that need no oracle: batch independence in eval mode, determinism, non-negativity."""
+    from r3m_amd import R3M
+    torch.manual_seed(0)
+    m = R3M("cuda", 1e-4, 1024, size=50, langweight=0.0, tcnweight=1.0).to(DEV)
+    m.eval()
+    x = torch.randint(0, 256, (40, 3, 224, 224), device=DEV).float()
+    with torch.no_grad():
+        h1 = m(x)
+        h2 = m(x)
+        h3 = m(x[8:24])
+    assert torch.equal(h1, h2)                      # bit-reproducible
+    assert (h1 >= 0).all()                          # avg-pool of ReLU
+    torch.testing.assert_close(h1[8:24], h3, rtol=1e-5, atol=1e-6)   # eval-mode frames are independent

@@ -1,0 +1,290 @@
+"""-m gpu: every HIP operator through the C ABI vs the PyTorch-CPU fp32 op the reference would run (fp32 tolerance written
+at each assert). Shapes cover every distinct conv geometry of ResNet-18/34/50 at small batch, plus
+ragged sizes that exercise the tile-edge masks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import nchw, nhwc, rel_err, rnd
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# (N, H, Ci, Co, k, stride, pad)
+CONV_CASES = [
+    (2, 56, 64, 64, 1, 1, 0), (2, 56, 64, 64, 3, 1, 1), (2, 56, 64, 256, 1, 1, 0), (2, 56, 256, 64, 1, 1, 0),
+    (2, 56, 256, 128, 1, 1, 0), (2, 56, 128, 128, 3, 2, 1), (2, 28, 128, 512, 1, 1, 0), (2, 56, 256, 512, 1, 2, 0),
+    (2, 28, 512, 128, 1, 1, 0), (2, 28, 128, 128, 3, 1, 1), (2, 28, 256, 256, 3, 2, 1), (3, 14, 256, 1024, 1, 1, 0),
+    (2, 28, 512, 1024, 1, 2, 0), (3, 14, 1024, 256, 1, 1, 0), (3, 14, 256, 256, 3, 1, 1), (3, 14, 512, 512, 3, 2, 1),
+    (5, 7, 512, 2048, 1, 1, 0), (3, 14, 1024, 2048, 1, 2, 0), (5, 7, 2048, 512, 1, 1, 0), (5, 7, 512, 512, 3, 1, 1),
+    (2, 56, 64, 128, 3, 2, 1), (2, 56, 64, 128, 1, 2, 0), (2, 28, 128, 256, 3, 2, 1), (3, 14, 256, 512, 3, 2, 1),
+    (3, 9, 64, 64, 3, 1, 1), (1, 11, 96, 192, 3, 2, 1), (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1),
+]
+
+
+def _ids(c):
+    return "N{}_H{}_{}to{}_k{}s{}p{}".format(*c)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=_ids)
+def test_conv_fwd_dgrad_wgrad(hip, case):
+    N, H, Ci, Co, k, s, p = case
+    x = rnd((N, Ci, H, H), 1)
+    w = rnd((Co, Ci, k, k), 2, -0.2, 0.2)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=s, padding=p)
+    Ho = y_ref.shape[2]
+    dy = rnd(tuple(y_ref.shape), 3)
+    y_ref.backward(dy)
+
+    xd = nhwc(x).to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)       # OHWI
+    yd = torch.empty((N, Ho, Ho, Co), device=DEV)
+    rows = hip.r3m_conv2d_stats_rows(N, H, H, Co, k, s, p)
+    stats = torch.zeros((rows, 2, Co), device=DEV)
+    rc = hip.r3m_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, st())
+    assert rc == 0, hip.r3m_last_error()
+    e_max, e_l2 = rel_err(nchw(yd.cpu()).numpy(), y_ref.detach().numpy())
+    assert e_max < 2e-5, f"conv fwd max-rel {e_max}"
+    # BatchNorm statistic partials: sum / sum of squares over rows, per output channel
+    ssum = stats[:, 0].double().sum(0).cpu().numpy()
+    ssq = stats[:, 1].double().sum(0).cpu().numpy()
+    yr = y_ref.detach().double()
+    np.testing.assert_allclose(ssum, yr.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3 * float(yr.abs().max()))
+    np.testing.assert_allclose(ssq, (yr * yr).sum((0, 2, 3)).numpy(), rtol=1e-4)
+
+    # dgrad
+    dyd = nhwc(dy).to(DEV)
+    dxd = torch.full((N, H, H, Ci), float("nan"), device=DEV)
+    wsb = hip.r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.r3m_conv2d_dgrad(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, st())
+    assert rc == 0, hip.r3m_last_error()
+    dx = nchw(dxd.cpu())
+    e_max, _ = rel_err(dx.numpy(), xr.grad.numpy())   # (strided 1x1: odd pixels must come back as exact zeros)
+    assert e_max < 2e-5, f"conv dgrad max-rel {e_max}"
+
+    # wgrad (+ accumulate)
+    dwd = torch.empty((Co, k, k, Ci), device=DEV)
+    wsb = hip.r3m_conv2d_wgrad_workspace_bytes(N, H, H, Ci, Co, k, s, p)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rc = hip.r3m_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, 0, st())
+    assert rc == 0, hip.r3m_last_error()
+    dw = dwd.cpu().permute(0, 3, 1, 2)
+    e_max, _ = rel_err(dw.numpy(), wr.grad.numpy())
+    assert e_max < 5e-5, f"conv wgrad max-rel {e_max}"
+    rc = hip.r3m_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, 1, st())
+    assert rc == 0
+    e_max, _ = rel_err(dwd.cpu().permute(0, 3, 1, 2).numpy(), 2 * wr.grad.numpy())
+    assert e_max < 5e-5, f"conv wgrad accumulate max-rel {e_max}"
+
+
+def test_conv_is_transpose_safe(hip):
+    """A = identity-like input against an ASYMMETRIC weight catches row/col swaps in the MFMA C layout."""
+    N, H, Ci, Co = 1, 8, 64, 128
+    x = torch.zeros((N, H, H, Ci))
+    for i in range(H * H):
+        x.view(-1, Ci)[i, i % Ci] = 1.0 + i
+    w = torch.arange(Co * Ci, dtype=torch.float32).view(Co, Ci, 1, 1) / 100.0
+    y_ref = F.conv2d(nchw(x), w)
+    yd = torch.empty((N, H, H, Co), device=DEV)
+    xd, wd = x.to(DEV), w.view(Co, 1, 1, Ci).contiguous().to(DEV)   # keep alive: launches are asynchronous
+    rc = hip.r3m_conv2d_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), None, N, H, H, Ci, Co, 1, 1, 0, st())
+    assert rc == 0
+    torch.testing.assert_close(nchw(yd.cpu()), y_ref, rtol=1e-6, atol=1e-5)
+
+
+def test_stem_im2col_conv(hip):
+    """x/255 -> Normalize -> conv 7x7/2 p3 (models_r3m.py:97-99) through the im2col + 160-wide GEMM route."""
+    Fr = 3
+    x = torch.floor(rnd((Fr, 3, 224, 224), 5, 0.0, 256.0)).clamp(0, 255)
+    w = rnd((64, 3, 7, 7), 6, -0.1, 0.1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    y_ref = F.conv2d((x / 255.0 - mean) / std, w, stride=2, padding=3)
+    col = torch.empty((Fr * 112 * 112, 160), device=DEV)
+    xd = x.to(DEV)
+    assert hip.r3m_stem_im2col(xd.data_ptr(), col.data_ptr(), Fr, st()) == 0
+    w160 = torch.zeros((64, 160))
+    w160[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
+    w160d = w160.to(DEV)
+    yd = torch.empty((Fr, 112, 112, 64), device=DEV)
+    rc = hip.r3m_conv2d_fwd(col.data_ptr(), w160d.data_ptr(), yd.data_ptr(), None, Fr * 112 * 112, 1, 1, 160, 64, 1, 1, 0, st())
+    assert rc == 0, hip.r3m_last_error()
+    e_max, _ = rel_err(nchw(yd.cpu()).numpy(), y_ref.numpy())
+    assert e_max < 2e-5
+
+
+@pytest.mark.parametrize("rows,C", [(2 * 56 * 56, 64), (3 * 14 * 14, 1024), (5 * 49, 2048), (777, 256), (33, 128)])
+@pytest.mark.parametrize("mode", ["plain", "identity", "downsample"])
+def test_bn_train_fwd_bwd(hip, rows, C, mode):
+    """BatchNorm2d(train) + [residual] + ReLU, forward and backward, vs torch CPU (F.batch_norm + autograd)."""
+    y = rnd((rows, C), 11, -2.0, 3.0)
+    gamma, beta = rnd((C,), 12, 0.5, 1.5), rnd((C,), 13, -0.3, 0.3)
+    rm, rv = rnd((C,), 14, -0.1, 0.1), rnd((C,), 15, 0.5, 1.5)
+    r = rnd((rows, C), 16, 0.0, 1.0)
+    y2 = rnd((rows, C), 17, -1.0, 1.0)
+    g2, b2 = rnd((C,), 18, 0.5, 1.5), rnd((C,), 19, -0.3, 0.3)
+    dz = rnd((rows, C), 20)
+
+    # ---- reference ----
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    t = F.batch_norm(yr.t().reshape(1, C, rows), rm_ref, rv_ref, gr, br, True, 0.1, 1e-5).reshape(C, rows).t()
+    if mode == "identity":
+        t = t + r
+    elif mode == "downsample":
+        y2r = y2.clone().requires_grad_(True)
+        g2r, b2r = g2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+        t = t + F.batch_norm(y2r.t().reshape(1, C, rows), None, None, g2r, b2r, True, 0.1, 1e-5).reshape(C, rows).t()
+    z_ref = torch.relu(t)
+    z_ref.backward(dz)
+
+    # ---- HIP: statistics come from a conv epilogue in production; emulate the partials layout [rows_blk][2][C] ----
+    def coeffs(yy, gg, bb, rmean, rvar):
+        blk = 128
+        nb = (rows + blk - 1) // blk
+        part = torch.zeros((nb, 2, C))
+        for i in range(nb):
+            sl = yy[i * blk:(i + 1) * blk]
+            part[i, 0] = sl.sum(0)
+            part[i, 1] = (sl * sl).sum(0)
+        coef = torch.empty((4, C), device=DEV)
+        wsb = hip.r3m_bn_workspace_bytes(rows, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        rmd = None if rmean is None else rmean.to(DEV)
+        rvd = None if rvar is None else rvar.to(DEV)
+        partd, ggd, bbd = part.to(DEV), gg.to(DEV), bb.to(DEV)   # keep alive across the async launches
+        rc = hip.r3m_bn_train_coeffs(partd.data_ptr(), nb, rows, ggd.data_ptr(), bbd.data_ptr(),
+                                     None if rmd is None else rmd.data_ptr(), None if rvd is None else rvd.data_ptr(), 0.1, 1e-5,
+                                     coef.data_ptr(), ws.data_ptr(), wsb, C, st())
+        assert rc == 0, hip.r3m_last_error()
+        torch.cuda.synchronize()
+        return coef, rmd, rvd
+
+    coef, rmd, rvd = coeffs(y, gamma, beta, rm, rv)
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv_ref.numpy(), rtol=1e-5, atol=1e-6)
+    yd, zd = y.to(DEV), torch.empty((rows, C), device=DEV)
+    coef2 = None
+    if mode == "plain":
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, st())
+    elif mode == "identity":
+        rd = r.to(DEV)
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), rd.data_ptr(), None, None, zd.data_ptr(), rows, C, 1, st())
+    else:
+        coef2, _, _ = coeffs(y2, g2, b2, None, None)
+        y2d = y2.to(DEV)
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, y2d.data_ptr(), coef2.data_ptr(), zd.data_ptr(), rows, C, 1, st())
+    assert rc == 0, hip.r3m_last_error()
+    e_max, _ = rel_err(zd.cpu().numpy(), z_ref.detach().numpy())
+    assert e_max < 1e-5, f"bn fwd {e_max}"
+
+    # ---- backward ----
+    dzd = dz.to(DEV)
+    wsb = hip.r3m_bn_workspace_bytes(rows, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dg, db, dyd = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty((rows, C), device=DEV)
+    zmask = None if mode == "plain" else zd
+    rc = hip.r3m_bn_bwd(dzd.data_ptr(), None if zmask is None else zmask.data_ptr(), yd.data_ptr(), coef.data_ptr(), dg.data_ptr(),
+                        db.data_ptr(), dyd.data_ptr(), ws.data_ptr(), wsb, rows, C, 1, 0, st())
+    assert rc == 0, hip.r3m_last_error()
+    assert rel_err(dyd.cpu().numpy(), yr.grad.numpy())[0] < 2e-4
+    assert rel_err(dg.cpu().numpy(), gr.grad.numpy())[0] < 1e-4
+    assert rel_err(db.cpu().numpy(), br.grad.numpy())[0] < 1e-4
+    if mode == "downsample":
+        rc = hip.r3m_bn_bwd(dzd.data_ptr(), zd.data_ptr(), y2d.data_ptr(), coef2.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                            dyd.data_ptr(), ws.data_ptr(), wsb, rows, C, 1, 0, st())
+        assert rc == 0
+        assert rel_err(dyd.cpu().numpy(), y2r.grad.numpy())[0] < 2e-4
+        assert rel_err(dg.cpu().numpy(), g2r.grad.numpy())[0] < 1e-4
+
+
+def test_bn_eval(hip):
+    rows, C = 500, 256
+    y = rnd((rows, C), 31, -2, 2)
+    gamma, beta, rm, rv = rnd((C,), 32, 0.5, 1.5), rnd((C,), 33, -0.3, 0.3), rnd((C,), 34, -0.2, 0.2), rnd((C,), 35, 0.5, 1.5)
+    z_ref = torch.relu(F.batch_norm(y.t().reshape(1, C, rows), rm, rv, gamma, beta, False, 0.1, 1e-5).reshape(C, rows).t())
+    coef = torch.empty((4, C), device=DEV)
+    gd, bd, rmd, rvd, yd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), y.to(DEV)
+    assert hip.r3m_bn_eval_coeffs(gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, coef.data_ptr(), C, st()) == 0
+    zd = torch.empty((rows, C), device=DEV)
+    assert hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, st()) == 0
+    assert rel_err(zd.cpu().numpy(), z_ref.numpy())[0] < 1e-5
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 112, 64), (3, 9, 64), (1, 10, 128)])
+def test_maxpool(hip, N, H, C):
+    z = torch.relu(rnd((N, C, H, H), 41))   # post-ReLU: plenty of exact-zero ties
+    zr = z.clone().requires_grad_(True)
+    p_ref = F.max_pool2d(zr, 3, 2, 1)
+    Ho = p_ref.shape[2]
+    dp = rnd(tuple(p_ref.shape), 42)
+    p_ref.backward(dp)
+    zd = nhwc(z).to(DEV)
+    pd = torch.empty((N, Ho, Ho, C), device=DEV)
+    am = torch.empty((N, Ho, Ho, C), dtype=torch.uint8, device=DEV)
+    assert hip.r3m_maxpool_fwd(zd.data_ptr(), pd.data_ptr(), am.data_ptr(), N, H, H, C, st()) == 0
+    torch.testing.assert_close(nchw(pd.cpu()), p_ref.detach(), rtol=0, atol=0)
+    dzd = torch.empty((N, H, H, C), device=DEV)
+    dpd = nhwc(dp).to(DEV)
+    assert hip.r3m_maxpool_bwd(dpd.data_ptr(), am.data_ptr(), dzd.data_ptr(), N, H, H, C, st()) == 0
+    # gradients may legitimately land on a different element of an all-zero (tied) window; after the ReLU mask they agree
+    mask = (z > 0).float()
+    torch.testing.assert_close(nchw(dzd.cpu()) * mask, zr.grad * mask, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(nchw(dzd.cpu()).sum(), zr.grad.sum(), rtol=1e-4, atol=1e-3)
+
+
+def test_avgpool(hip):
+    N, HW, C = 6, 49, 2048
+    x = rnd((N, HW, C), 51)
+    hd = torch.empty((N, C), device=DEV)
+    xd = x.to(DEV)
+    assert hip.r3m_avgpool_fwd(xd.data_ptr(), hd.data_ptr(), N, HW, C, st()) == 0
+    ref = F.adaptive_avg_pool2d(x.permute(0, 2, 1).reshape(N, C, 7, 7), 1).flatten(1)
+    assert rel_err(hd.cpu().numpy(), ref.numpy())[0] < 1e-6
+    dh = rnd((N, C), 52)
+    dxd = torch.empty((N, HW, C), device=DEV)
+    dhd = dh.to(DEV)
+    assert hip.r3m_avgpool_bwd(dhd.data_ptr(), dxd.data_ptr(), N, HW, C, st()) == 0
+    torch.testing.assert_close(dxd.cpu(), (dh / 49.0).unsqueeze(1).expand(N, HW, C), rtol=1e-6, atol=1e-7)
+
+
+def test_linear(hip):
+    M, K, Nn = 120, 1792, 1024
+    x, w, b = rnd((M, K), 61), rnd((Nn, K), 62, -0.05, 0.05), rnd((Nn,), 63)
+    yd = torch.empty((M, Nn), device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    assert hip.r3m_linear_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), M, K, Nn, 1, st()) == 0
+    ref = torch.relu(F.linear(x, w, b))
+    assert rel_err(yd.cpu().numpy(), ref.numpy())[0] < 2e-5
+
+
+def test_adam_matches_torch(hip):
+    """G6: 3 steps vs torch.optim.Adam defaults (models_r3m.py:76)."""
+    n = 4096 + 64
+    p0 = rnd((n,), 71)
+    grads = [rnd((n,), 72 + i, -0.01, 0.01) * (10.0 ** (i - 1)) for i in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4)
+    pd = p0.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(grads):
+        pr.grad = g.clone()
+        opt.step()
+        gd = g.to(DEV)
+        assert hip.r3m_adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, i + 1, 1.0, st()) == 0
+        torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(m.cpu(), opt.state[pr]["exp_avg"], rtol=1e-6, atol=1e-12)
+    torch.testing.assert_close(v.cpu(), opt.state[pr]["exp_avg_sq"], rtol=1e-6, atol=1e-14)
