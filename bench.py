@@ -33,20 +33,26 @@ def cpu_baseline(size, clips, seconds_budget=25.0):
     """The oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this box's host cores, bounded sample."""
     from oracle import r3m_ref
     torch.manual_seed(1)
-    n_thr = os.cpu_count() or 1
+    # physical cores of one socket are the useful ceiling for MKLDNN convs at this batch; 256 SMT threads thrash (measured
+    # 0.22 frames/s at 256 threads on the 2 x EPYC 9575F host), so cap at 64 and report what was used
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_thr = max(1, min(64, avail // 2 if avail >= 4 else avail))
     torch.set_num_threads(n_thr)
     ref = r3m_ref.R3MRef(size=size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
     g = torch.Generator().manual_seed(1234)
     frames = torch.randint(0, 256, (clips, 5, 3, 224, 224), generator=g).float()
     perms = torch.stack([torch.randperm(clips) for _ in range(6)])
+    t_w = time.time()
     r3m_ref.train_step_ref(ref, frames, tcn_perm=perms)   # warm-up
+    t_w = time.time() - t_w
     times = []
     t_end = time.time() + seconds_budget
-    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
+    min_steps = 3 if t_w < seconds_budget / 3 else 1
+    while len(times) < min_steps or (time.time() < t_end and len(times) < 8):
         t0 = time.time()
         r3m_ref.train_step_ref(ref, frames, tcn_perm=perms)
         times.append(time.time() - t0)
-        if time.time() > t_end and len(times) >= 3:
+        if time.time() > t_end and len(times) >= min_steps:
             break
     best = min(times)
     cpu_model = "unknown"
@@ -72,6 +78,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="clips per GPU (5 frames each); BASELINE bs=256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
+    ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +115,8 @@ def main():
     for i in range(args.warmup):
         trainer.update(net, (frames, langs), i)
     L.r3m_profile_enable(1)
+    if args.launch_csv and rank == 0:
+        _lib.check(L.r3m_profile_dump_to(args.launch_csv.encode()), "profile_dump_to")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -117,6 +126,7 @@ def main():
     ms, launches, flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
     _lib.check(L.r3m_profile_collect(ms, launches, flops), "profile_collect")
     L.r3m_profile_enable(0)
+    L.r3m_profile_dump_to(None)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

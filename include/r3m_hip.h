@@ -29,6 +29,7 @@ const char* r3m_last_error(void);
  * FLOPs per class since the last collect (arrays of 4) and resets. */
 void r3m_profile_enable(int on);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
+int r3m_profile_dump_to(const char* host_path);   /* also write one CSV row per launch at collect(); NULL/"" stops */
 
 /* ---------------- encoder engine -----------------------------------------------------------------------------
  * Replaces torchvision.models.resnet{18,34,50}(pretrained=False) with fc=Identity as built by R3M.__init__
@@ -97,6 +98,19 @@ int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream
 /* nn.Linear (+ReLU) of LanguageReward.pred (r3m/models/models_language.py:43-51): y[M,N] = x[M,K] w[N,K]^T + b */
 int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu,
                    r3m_stream_t stream);
+
+/* LanguageReward, all 15 evaluations of a step batched (r3m/trainer.py:72-92 calling r3m/models/models_r3m.py:78-81 and
+ * r3m/models/models_language.py:43-55). alle [B,5,D]; feats [B,lang_dim] = frozen sentence features (LangEncoder output,
+ * NOT permuted); perm/iperm [9][B] int32 = the reference's torch.randperm draws in order (a,b,c) x 3 (trainer.py:86-92) and
+ * their inverses; params/grads = flat pred.{0,2,4,6,8}.{weight,bias} in state-dict order (r3m_langrew_num_params floats).
+ * forward leaves the activations in `workspace`; backward consumes them, writes parameter gradients (= or +=) and ADDS
+ * d/d alle into dalle [B,5,D] (may be NULL). scores/dscore are [15][B] in the reference's call order. */
+long long r3m_langrew_num_params(int D, int hidden, int lang_dim);
+size_t r3m_langrew_workspace_bytes(int B, int D, int hidden, int lang_dim);
+int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* workspace,
+                        size_t workspace_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream);
+int r3m_langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* workspace,
+                         size_t workspace_bytes, int B, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream);
 
 /* ---------------- objective (r3m/trainer.py:39-152, R3M.sim models_r3m.py:102-107) ----------------------------
  * alle [B,5,D] (e0, eg, es0, es1, es2 per clip); perm/iperm [6][B] int32: the reference's torch.randperm draws in

@@ -24,6 +24,7 @@ SIGNATURES = {
     "r3m_last_error": (C.c_char_p, []),
     "r3m_profile_enable": (None, [c_i]),
     "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
+    "r3m_profile_dump_to": (c_i, [C.c_char_p]),
     "r3m_resnet_create": (C.c_void_p, [c_i, c_i]),
     "r3m_resnet_destroy": (None, [C.c_void_p]),
     "r3m_resnet_out_dim": (c_i, [C.c_void_p]),
@@ -53,6 +54,10 @@ SIGNATURES = {
     "r3m_avgpool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     "r3m_avgpool_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     "r3m_linear_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_num_params": (c_ll, [c_i, c_i, c_i]),
+    "r3m_langrew_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "r3m_langrew_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_backward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_loss_workspace_bytes": (c_sz, [c_i]),
     "r3m_loss_tcn_lp": (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f]),
     "r3m_loss_lang_infonce": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_fl, c_f]),

@@ -28,13 +28,13 @@ int check_launch(const char* what) {
 }
 
 // ---- per-kernel-class event timing ----
-struct ProfEvent { hipEvent_t a, b; int kclass; double flops; };
+struct ProfEvent { hipEvent_t a, b; int kclass; double flops; int M, N, K, taps; };
 static bool g_prof_on = false;
 static std::vector<ProfEvent> g_prof_pool;
 static size_t g_prof_used = 0;
 static bool g_prof_open = false;
 
-void prof_begin(int kclass, double flops, hipStream_t s) {
+void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStream_t s) {
   if (!g_prof_on) return;
   if (g_prof_used == g_prof_pool.size()) {
     ProfEvent e;
@@ -42,7 +42,7 @@ void prof_begin(int kclass, double flops, hipStream_t s) {
     g_prof_pool.push_back(e);
   }
   ProfEvent& e = g_prof_pool[g_prof_used];
-  e.kclass = kclass; e.flops = flops;
+  e.kclass = kclass; e.flops = flops; e.M = M; e.N = N; e.K = K; e.taps = taps;
   (void)hipEventRecord(e.a, s);
   g_prof_open = true;
 }
@@ -86,6 +86,13 @@ int launch_loss_finalize(float* ws, int B, int have_lang, float* metrics, float 
                          hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                 long long step, float grad_scale, hipStream_t s);
+// lang.hip
+long long langrew_num_params(int D, int H, int LD);
+size_t langrew_ws_floats(int B, int D, int H, int LD);
+int langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, float* ws, int B,
+                    int D, int H, int LD, hipStream_t s);
+int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
+                     int H, int LD, int accumulate, hipStream_t s);
 
 }  // namespace r3m
 
@@ -99,6 +106,17 @@ extern "C" {
 int r3m_abi_version(void) { return 1; }
 
 void r3m_profile_enable(int on) { g_prof_on = on != 0; if (!on) g_prof_used = 0; }
+// optional: every launch since the last collect as CSV rows (class,M,N,K,taps,ms,gflop) into a host file
+static FILE* g_prof_dump = nullptr;
+int r3m_profile_dump_to(const char* path) {
+  if (g_prof_dump) { fclose(g_prof_dump); g_prof_dump = nullptr; }
+  if (path && *path) {
+    g_prof_dump = fopen(path, "w");
+    if (!g_prof_dump) { set_last_error("profile_dump_to: cannot open %s", path); return 1; }
+    fprintf(g_prof_dump, "class,M,N,K,taps,ms,gflop\n");
+  }
+  return 0;
+}
 int r3m_profile_collect(double* ms, long long* launches, double* flops) {
   for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; flops[k] = 0.0; }
   for (size_t i = 0; i < g_prof_used; ++i) {
@@ -107,8 +125,10 @@ int r3m_profile_collect(double* ms, long long* launches, double* flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { set_last_error("profile_collect: elapsed failed"); return 1; }
     ms[e.kclass] += t; launches[e.kclass] += 1; flops[e.kclass] += e.flops;
+    if (g_prof_dump) fprintf(g_prof_dump, "%d,%d,%d,%d,%d,%.4f,%.3f\n", e.kclass, e.M, e.N, e.K, e.taps, t, e.flops * 1e-9);
   }
   g_prof_used = 0;
+  if (g_prof_dump) fflush(g_prof_dump);
   return 0;
 }
 const char* r3m_last_error(void) { return g_err; }
@@ -215,6 +235,21 @@ int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream
 
 int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu, r3m_stream_t stream) {
   return conv_forward_launch(x, w, y, nullptr, bias, M, 1, 1, K, N, 1, 1, 0, (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0), S(stream));
+}
+
+long long r3m_langrew_num_params(int D, int hidden, int lang_dim) { return langrew_num_params(D, hidden, lang_dim); }
+size_t r3m_langrew_workspace_bytes(int B, int D, int hidden, int lang_dim) { return langrew_ws_floats(B, D, hidden, lang_dim) * 4; }
+int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* ws,
+                        size_t ws_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream) {
+  R3M_REQUIRE(alle && feats && perm && params && scores && ws, "langrew_forward: null argument");
+  R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_forward: workspace too small");
+  return langrew_forward(alle, feats, perm, params, scores, static_cast<float*>(ws), B, D, hidden, lang_dim, S(stream));
+}
+int r3m_langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* ws,
+                         size_t ws_bytes, int B, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream) {
+  R3M_REQUIRE(dscore && iperm && params && grads && ws, "langrew_backward: null argument");
+  R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_backward: workspace too small");
+  return langrew_backward(dscore, iperm, params, grads, dalle, static_cast<float*>(ws), B, D, hidden, lang_dim, accumulate, S(stream));
 }
 
 size_t r3m_loss_workspace_bytes(int B) { return loss_workspace_floats(B) * 4; }

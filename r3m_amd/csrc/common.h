@@ -31,7 +31,7 @@ enum : int {
   EPI_MASKED_ADD = 4,   // out = acc + add0 * (add1 > 0)   (residual gradient joining a dgrad)
   EPI_BIAS       = 8,   // out = acc + bias[col]
   EPI_RELU       = 16,  // out = max(out, 0)
-  EPI_BT_NK      = 32,  // (unused by conv) reserved
+  EPI_MASK_OUT   = 32,  // out = (add1 > 0) ? acc : 0        (ReLU backward fused into a Linear dgrad)
 };
 
 constexpr int MAX_TAPS = 49;
@@ -108,7 +108,7 @@ int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStre
 
 // ---- optional per-kernel-class HIP-event timing (bench.py roofline; off by default, zero cost when off) ----
 enum { KC_GEMM_WIDE = 0, KC_GEMM_NARROW = 1, KC_WGRAD_WIDE = 2, KC_WGRAD_NARROW = 3, KC_COUNT = 4 };
-void prof_begin(int kclass, double flops, hipStream_t s);   // records the start event (no-op when disabled)
+void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStream_t s);   // start event (no-op when disabled)
 void prof_end(hipStream_t s);                                // records the stop event
 
 }  // namespace r3m

@@ -13,6 +13,7 @@
 //       bias (+ReLU).
 //   * wgrad_kernel       : dW[co, tap, ci] = sum_m dY[m, co] * in[pix(m) + off(tap), ci]   (split-K over m)
 #include "common.h"
+#include <cstdlib>
 
 namespace r3m {
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // step j of group g contracts k = {8g+j, 8g+4+j}. A and B use the same k permutation, the sum is unchanged.
 // The 36-float stride makes both the b128 fragment reads and the b128 staging writes bank-conflict free.
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams p) {
   constexpr int S = 36;
   constexpr int TM = BM / WM / 32;
@@ -162,42 +163,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  const int flags = p.flags;
-  const bool out_simple = (p.os == 1);
-  const int hwg = p.Hg * p.Wg;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= p.M) continue;
-      long long roff;
-      if (out_simple) {
-        roff = (long long)row * p.Nc;
-      } else {
-        const int n = row / hwg;
-        const int rem = row - n * hwg;
-        const int gy = rem / p.Wg;
-        const int gx = rem - gy * p.Wg;
-        roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + (wn * TN + tn) * 32 + lrow;
-        if (col >= p.Nc) continue;
-        float v = acc[tm][tn][r];
-        const long long off = roff + col;
-        if (flags & EPI_BIAS) v += p.bias[col];
-        if (flags & EPI_ACCUM) v += p.out[off];
-        if (flags & EPI_MASKED_ADD) v += (p.add1[off] > 0.f) ? p.add0[off] : 0.f;
-        if (flags & EPI_RELU) v = fmaxf(v, 0.f);
-        p.out[off] = v;
-      }
-    }
-  }
-
-  if (flags & EPI_STATS) {
+  // ---- BatchNorm statistic partials straight from the accumulators ----
+  if (EPI & EPI_STATS) {
     // rows >= M were staged as zeros -> their accumulators are exactly 0 and add nothing to either sum
     float* red = smem;  // [WM][2][BN]; the K loop ended with a barrier, the tiles are dead
 #pragma unroll
@@ -233,6 +200,69 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
         p.stats[((long long)mt * 2 + 1) * p.Nc + col] = ss;
       }
     }
+    __syncthreads();
+  }
+
+  // ---- output: each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store
+  // instruction writes 4 rows x 256 contiguous bytes (dwordx4 per lane) instead of 2 rows x 128 B of single dwords ----
+  constexpr int CW = TN * 32;          // columns owned by the wave
+  constexpr int CS = CW + 4;           // padded slab row stride (floats)
+  constexpr int F4 = CW / 4;           // float4 per slab row
+  constexpr int RPI = 64 / F4;         // rows covered per store instruction
+  static_assert(4 * 32 * CS <= (BM + BN) * S, "epilogue slab must fit in the operand tiles' LDS");
+  float* slab = smem + wave * 32 * CS;
+  const bool out_simple = (p.os == 1);
+  const int hwg = p.Hg * p.Wg;
+  const int ecol = (lane % F4) * 4;
+  const int erow = lane / F4;
+  const int gcol = n0 + wn * CW + ecol;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if ((EPI & EPI_BIAS) && gcol < p.Nc) bias4 = ldg4(p.bias + gcol);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int lr = it * RPI + erow;
+      const int row = m0 + (wm * TM + tm) * 32 + lr;
+      if (row < p.M && gcol < p.Nc) {
+        long long roff;
+        if (out_simple) {
+          roff = (long long)row * p.Nc;
+        } else {
+          const int n = row / hwg;
+          const int rem = row - n * hwg;
+          const int gy = rem / p.Wg;
+          const int gx = rem - gy * p.Wg;
+          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
+        float* dst = p.out + roff + gcol;
+        if (EPI & EPI_BIAS) v += bias4;
+        if (EPI & EPI_ACCUM) v += ldg4(dst);
+        if (EPI & EPI_MASKED_ADD) {
+          const f32x4 g = ldg4(p.add0 + roff + gcol), z = ldg4(p.add1 + roff + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (z[e] > 0.f) ? g[e] : 0.f;
+        }
+        if (EPI & EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (EPI & EPI_MASK_OUT) {
+          const f32x4 z = ldg4(p.add1 + roff + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -240,25 +270,52 @@ static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 int gather_gemm_grid_m(int M, int Nc) { return gg_wide(Nc) ? ceil_div(M, 128) : ceil_div(M, 256); }
 
+template <int BM, int BN, int WM, int WN>
+static int gg_dispatch_epi(const GatherGemmParams& p, int grid, hipStream_t s) {
+  const int f = p.flags;
+#define GG_CASE(E)                                                                                                   \
+  case E:                                                                                                            \
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, E>), dim3(grid), dim3(256), 0, s, p);                \
+    return 0;
+  switch (f) {
+    GG_CASE(0)
+    GG_CASE(EPI_STATS)
+    GG_CASE(EPI_ACCUM)
+    GG_CASE(EPI_MASKED_ADD)
+    GG_CASE(EPI_BIAS)
+    GG_CASE(EPI_RELU)
+    GG_CASE(EPI_BIAS | EPI_RELU)
+    GG_CASE(EPI_MASK_OUT)
+    default:
+      set_last_error("gather_gemm: unsupported epilogue flag combination %d", f);
+      return 1;
+  }
+#undef GG_CASE
+}
+
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 32 == 0, "gather_gemm: Ci=%d must be a multiple of 32", p.Ci);
+  R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm: Nc=%d must be a multiple of 4", p.Nc);
   R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
   R3M_REQUIRE(p.M > 0 && p.Nc > 0, "gather_gemm: empty problem M=%d Nc=%d", p.M, p.Nc);
-  R3M_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0,
+  R3M_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
               "gather_gemm: operands must be 16-byte aligned");
   // algorithmic FLOPs: the stem arrives as 160-wide patch rows of which 147 are real (7*7*3)
   const double kdim = (double)p.ntaps * (p.Ci == 160 ? 147 : p.Ci);
   const double flops = 2.0 * (double)p.M * (double)p.Nc * kdim;
+  int rc;
   if (gg_wide(p.Nc)) {
     const int gm = ceil_div(p.M, 128), gn = ceil_div(p.Nc, 128);
-    prof_begin(KC_GEMM_WIDE, flops, s);
-    hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2>), dim3(gm * gn), dim3(256), 0, s, p);
+    prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    rc = gg_dispatch_epi<128, 128, 2, 2>(p, gm * gn, s);
   } else {
     const int gm = ceil_div(p.M, 256), gn = ceil_div(p.Nc, 64);
-    prof_begin(KC_GEMM_NARROW, flops, s);
-    hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1>), dim3(gm * gn), dim3(256), 0, s, p);
+    prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    rc = gg_dispatch_epi<256, 64, 4, 1>(p, gm * gn, s);
   }
   prof_end(s);
+  if (rc) return rc;
   return check_launch("gather_gemm");
 }
 
@@ -400,12 +457,12 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
   if (wg_wide(p.Co, p.Ci)) {
     p.tilesN = ceil_div(p.Ci, 128);
     const int tiles = ceil_div(p.Co, 128) * p.tilesN * T;
-    prof_begin(KC_WGRAD_WIDE, flops, s);
+    prof_begin(KC_WGRAD_WIDE, flops, p.M, p.Co, p.Ci, T, s);
     hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
-    prof_begin(KC_WGRAD_NARROW, flops, s);
+    prof_begin(KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
     hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
   }
   prof_end(s);

@@ -1,0 +1,219 @@
+"""Language side of R3M on the HIP path — same classes as /root/reference/r3m/models/models_language.py:
+
+  LangEncoder(device, finetune=False, scratch=False)   frozen DistilBERT sentence features, lang_size = 768   (:13-35)
+  LanguageReward(ltype, im_dim, hidden_dim, lang_dim, simfunc=None)   MLP [2D+768 -> H -> H -> H -> H -> 1]    (:37-55)
+
+What changes is the schedule, not the math: the reference calls get_reward 15 times per step and re-runs DistilBERT each
+time on the same sentences (trainer.py:72-92). Here the sentence features are computed once per step and the 15 MLP
+evaluations are one batched [15B, 2D+768] pass in csrc/lang.hip (`LanguageReward.batched_scores`).
+
+DistilBERT itself is a frozen feature extractor outside the kernel scope: LangEncoder accepts
+precomputed [B,768] features (BASELINE config 3: "frozen DistilBERT text feats"), a sentence->feature cache, or, when the
+HuggingFace weights are on disk, runs the model once per batch with the reference's mean-over-all-positions pooling.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import inverse_permutations
+
+epsilon = 1e-8
+
+
+class LangEncoder(nn.Module):
+    def __init__(self, device, finetune=False, scratch=False):
+        super().__init__()
+        self.device = device
+        self.modelname = "distilbert-base-uncased"
+        self.lang_size = 768
+        self.feature_cache = {}       # sentence -> [768] tensor (offline-precomputed features)
+        self._hf = None               # (tokenizer, model), loaded lazily from local files only
+
+    def _load_hf(self):
+        if self._hf is None:
+            try:
+                from transformers import AutoModel, AutoTokenizer
+                tok = AutoTokenizer.from_pretrained(self.modelname, local_files_only=True)
+                model = AutoModel.from_pretrained(self.modelname, local_files_only=True).to(self.device)
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(
+                    "r3m_amd.LangEncoder: sentence strings were passed but the DistilBERT weights "
+                    f"({self.modelname}) are not available locally ({type(e).__name__}). Pass precomputed [B,768] "
+                    "features instead of strings, or fill LangEncoder.feature_cache.") from e
+            model.eval()
+            self._hf = (tok, model)
+        return self._hf
+
+    def forward(self, langs):
+        if torch.is_tensor(langs):                     # precomputed frozen features
+            return langs
+        try:
+            langs = langs.tolist()
+        except AttributeError:
+            pass
+        if langs and all(s in self.feature_cache for s in langs):
+            return torch.stack([self.feature_cache[s] for s in langs]).to(self.device)
+        tok, model = self._load_hf()
+        with torch.no_grad():                          # models_language.py:29-34
+            enc = tok(langs, return_tensors="pt", padding=True)
+            out = model(enc["input_ids"].to(self.device), attention_mask=enc["attention_mask"].to(self.device)).last_hidden_state
+            return out.mean(1)                         # mean over ALL positions incl. padding, as the reference does
+
+
+class _Node(nn.Module):
+    pass
+
+
+class _BatchedRewardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alle, feats, perm, anchor, module):
+        L = _lib.lib()
+        B, _, D = alle.shape
+        alle = alle.contiguous()
+        feats = feats.to(dtype=torch.float32).contiguous()
+        perm = perm.to(device=alle.device, dtype=torch.int32).contiguous()
+        ws_bytes = L.r3m_langrew_workspace_bytes(B, D, module.hidden_dim, module.lang_dim)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=alle.device)
+        scores = torch.empty((15, B), dtype=torch.float32, device=alle.device)
+        _lib.check(L.r3m_langrew_forward(alle.data_ptr(), feats.data_ptr(), perm.data_ptr(), module.flat_params().data_ptr(),
+                                         scores.data_ptr(), ws.data_ptr(), ws_bytes, B, D, module.hidden_dim, module.lang_dim,
+                                         _lib.stream_ptr()), "langrew_forward")
+        ctx.module, ctx.ws, ctx.ws_bytes, ctx.dims = module, ws, ws_bytes, (B, D)
+        ctx.save_for_backward(perm)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        L = _lib.lib()
+        (perm,) = ctx.saved_tensors
+        module = ctx.module
+        B, D = ctx.dims
+        iperm = inverse_permutations(perm).contiguous()
+        dalle = torch.zeros((B, 5, D), dtype=torch.float32, device=dscores.device)
+        g = module.flat_grads()
+        accumulate = 0 if module._grad_fresh else 1
+        _lib.check(L.r3m_langrew_backward(dscores.contiguous().data_ptr(), iperm.data_ptr(), module.flat_params().data_ptr(),
+                                          g.data_ptr(), dalle.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes, B, D, module.hidden_dim,
+                                          module.lang_dim, accumulate, _lib.stream_ptr()), "langrew_backward")
+        module._grad_fresh = False
+        module._has_grads = True
+        ctx.ws = None
+        return dalle, None, None, None, None
+
+
+class LanguageReward(nn.Module):
+    def __init__(self, ltype, im_dim, hidden_dim, lang_dim, simfunc=None):
+        super().__init__()
+        self.ltype = ltype
+        self.sim = simfunc
+        self.sigm = nn.Sigmoid()
+        self.im_dim, self.hidden_dim, self.lang_dim = im_dim, hidden_dim, lang_dim
+        dims = [(hidden_dim, 2 * im_dim + lang_dim)] + [(hidden_dim, hidden_dim)] * 3 + [(1, hidden_dim)]
+        n = sum(o * i + o for o, i in dims)
+        self._n = n
+        self._n_padded = (n + 3) // 4 * 4            # the fused Adam kernel works on float4
+        self._layout = []                             # (name, offset, shape)
+        flat = torch.zeros(self._n_padded, dtype=torch.float32)
+        self.pred = _Node()
+        off = 0
+        for li, (o, i) in zip((0, 2, 4, 6, 8), dims):  # nn.Sequential indices of the Linear layers (models_language.py:43-51)
+            node = _Node()
+            self.pred.add_module(str(li), node)
+            node.register_parameter("weight", nn.Parameter(flat[off:off + o * i].view(o, i)))
+            self._layout.append((f"pred.{li}.weight", off, (o, i)))
+            off += o * i
+            node.register_parameter("bias", nn.Parameter(flat[off:off + o].view(o)))
+            self._layout.append((f"pred.{li}.bias", off, (o,)))
+            off += o
+        self._flat_p = flat
+        self._flat_g = None
+        self._grad_fresh = True
+        self._has_grads = False
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """nn.Linear default init (kaiming_uniform(a=sqrt(5)) weight, U(-1/sqrt(fan_in), 1/sqrt(fan_in)) bias)."""
+        P = dict(self.named_parameters())
+        with torch.no_grad():
+            for name, off, shape in self._layout:
+                if len(shape) == 2:
+                    nn.init.kaiming_uniform_(P[name], a=math.sqrt(5))
+                else:
+                    fan_in = P[name.replace("bias", "weight")].shape[1]
+                    bound = 1 / math.sqrt(fan_in)
+                    nn.init.uniform_(P[name], -bound, bound)
+
+    # ---- flat storage (same protocol as HipResNet) ----
+    def _is_flat(self):
+        P = dict(self.named_parameters())
+        base, dev = self._flat_p.data_ptr(), self._flat_p.device
+        return all(P[n].device == dev and P[n].data_ptr() == base + off * 4 for n, off, _ in self._layout)
+
+    def _reflatten(self):
+        P = dict(self.named_parameters())
+        dev = next(iter(P.values())).device
+        flat = torch.zeros(self._n_padded, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, off, shape in self._layout:
+                v = flat[off:off + math.prod(shape)].view(shape)
+                v.copy_(P[name])
+                P[name].data = v
+                P[name].grad = None
+        self._flat_p, self._flat_g, self._grad_fresh, self._has_grads = flat, None, True, False
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._reflatten()
+        return self
+
+    def flat_params(self):
+        if not self._is_flat():
+            self._reflatten()
+        return self._flat_p
+
+    def flat_grads(self):
+        self.flat_params()
+        if self._flat_g is None:
+            self._flat_g = torch.zeros_like(self._flat_p)
+            P = dict(self.named_parameters())
+            for name, off, shape in self._layout:
+                P[name].grad = self._flat_g[off:off + math.prod(shape)].view(shape)
+        return self._flat_g
+
+    def mark_grads_stale(self):
+        self._grad_fresh = True
+
+    def has_grads(self):
+        return self._has_grads
+
+    # ---- compute ----
+    def batched_scores(self, alle, feats, lang_perm):
+        """All 15 reward evaluations of Trainer.update in one pass. alle [B,5,D] (requires grad), feats [B,lang_dim] frozen,
+        lang_perm [9,B] = the reference's randperm draws (trainer.py:86-92). Returns scores [15,B] (rows: pos1-3, in-clip
+        negatives 1-3, then for each k the permuted negatives of heads 1-3)."""
+        if not alle.is_cuda:
+            raise RuntimeError("r3m_amd.LanguageReward runs on the HIP path only (no CPU fallback)")
+        anchor = self.pred._modules["0"].weight
+        return _BatchedRewardFn.apply(alle, feats, lang_perm, anchor, self)
+
+    def forward(self, e0, eg, le):
+        """Single evaluation G(e0, eg, le) -> (score[B], {}), reference signature (models_language.py:53-55). Inference helper:
+        runs the HIP Linear chain without autograd; training goes through batched_scores()."""
+        if not e0.is_cuda:
+            raise RuntimeError("r3m_amd.LanguageReward runs on the HIP path only (no CPU fallback)")
+        L = _lib.lib()
+        with torch.no_grad():
+            x = torch.cat([e0, eg, le.to(e0.dtype)], -1).contiguous()
+            M = x.shape[0]
+            P = dict(self.named_parameters())
+            st = _lib.stream_ptr()
+            for li in (0, 2, 4, 6):
+                w, b = P[f"pred.{li}.weight"], P[f"pred.{li}.bias"]
+                y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=x.device)
+                _lib.check(L.r3m_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, w.shape[1], w.shape[0], 1, st),
+                           "linear_fwd")
+                x = y
+            score = x @ P["pred.8.weight"].t() + P["pred.8.bias"]
+        return score.squeeze(), {}

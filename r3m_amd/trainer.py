@@ -51,8 +51,18 @@ class Trainer:
             tcn_perm = tcn_perm.to(alle.device, non_blocking=True)
 
         if core.langweight > 0:
-            scores = core.lang_rew.batched_scores(alle, core.lang_enc(b_lang), lang_perm.to(alle.device))
-            mask = torch.tensor([1.0 * (b != "") for b in b_lang], dtype=torch.float32, device=alle.device)
+            # b_lang: list[str] as in the reference, or precomputed frozen features [B,768] / (features, mask[B])
+            lang_mask = None
+            if isinstance(b_lang, (tuple, list)) and len(b_lang) == 2 and torch.is_tensor(b_lang[0]):
+                b_lang, lang_mask = b_lang
+            feats = core.lang_enc(b_lang).to(alle.device)
+            scores = core.lang_rew.batched_scores(alle, feats, lang_perm.to(alle.device))
+            if lang_mask is not None:
+                mask = lang_mask.to(device=alle.device, dtype=torch.float32)
+            elif torch.is_tensor(b_lang):
+                mask = torch.ones(bs, dtype=torch.float32, device=alle.device)
+            else:   # videos without language are masked out (trainer.py:107-109)
+                mask = torch.tensor([1.0 * (b != "") for b in b_lang], dtype=torch.float32, device=alle.device)
         t5 = time.time()
 
         full_loss, m = ops.r3m_loss(alle, tcn_perm, core.l2weight, core.l1weight, core.tcnweight, l2dist=core.l2dist,

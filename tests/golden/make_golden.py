@@ -64,6 +64,32 @@ def encoder_golden(size, F=8):
     print("encoder", size, out["h_train"].shape, float(np.abs(out["h_train"]).max()))
 
 
+def encoder_fp64_golden(size, F=8):
+    """Noise-floor reference: the SAME graph evaluated in float64 with the oracle restatement (oracle/r3m_ref.py). Used to
+    express gradient tolerances relative to the reference's own fp32 round-off (its fp32 gradients sit ~5e-3 l2-rel away
+    from fp64 at conv1 for ResNet-18, more for deeper nets)."""
+    from oracle import r3m_ref
+    g32 = np.load(os.path.join(OUT, f"encoder_r{size}.npz"))
+    m = r3m_ref.R3MRef(size=size, langweight=0.0, tcnweight=1.0)
+    set_state(m.convnet)
+    m = m.double()
+    x = torch.from_numpy(detgen.frames(f"frames{F}", (F, 3, 224, 224))).double()
+    m.train()
+    h = m.convnet(m.normlayer(x / 255.0))
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).double()
+    (h * cw).sum().backward()
+    P = dict(m.convnet.named_parameters())
+    lb = last_bn_name(size)
+    out = {"h_train": h.detach().numpy(), "grad_names": g32["grad_names"],
+           "grad_norms": np.array([float(P[str(n)].grad.norm()) for n in g32["grad_names"]])}
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",
+              "layer2.0.downsample.0.weight"):
+        out["grad_" + k] = P[k].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"encoder_r{size}_fp64.npz"), **out)
+    e = np.linalg.norm(g32["grad_conv1.weight"].astype(np.float64) - P["conv1.weight"].grad.numpy()) / np.linalg.norm(P["conv1.weight"].grad.numpy())
+    print("fp64", size, "reference-fp32 conv1.weight grad l2-rel vs fp64:", e)
+
+
 class _FakeCore(torch.nn.Module):
     """Stands where `model.module` does in the reference Trainer: loss weights, sim, get_reward with fixed text features."""
 
@@ -191,6 +217,7 @@ if __name__ == "__main__":
     assert by_path.available(), "/root/reference is required to (re)generate goldens"
     for size in (18, 34, 50):
         encoder_golden(size)
+        encoder_fp64_golden(size)
     loss_golden(True)
     loss_golden(False)
     step_golden()

@@ -1,0 +1,105 @@
+"""-m gpu: language-reward head (batched 15-call MLP, csrc/lang.hip) + language InfoNCE, against the reference's own
+Trainer.update run (tests/golden/loss_*.npz, G3) and against the CPU oracle for a full step with langweight = 1."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lang_state(module):
+    from oracle import detgen
+    sd = {}
+    full = module.state_dict()
+    for k, v in full.items():
+        fan_in = v.shape[1] if v.dim() == 2 else full[k.replace("bias", "weight")].shape[1]
+        a = 1.0 / np.sqrt(fan_in)
+        sd[k] = torch.from_numpy(detgen.uniform("lr" + k, tuple(v.shape), -a, a))
+    return sd
+
+
+@pytest.mark.parametrize("l2dist", [True, False])
+def test_full_loss_with_language_matches_reference_golden(hip, golden_dir, l2dist):
+    from oracle import detgen
+    from r3m_amd import ops
+    from r3m_amd.models_language import LanguageReward
+    sys.path.insert(0, golden_dir)
+    from make_golden import make_alle
+    g = np.load(os.path.join(golden_dir, f"loss_{'l2' if l2dist else 'cos'}.npz"))
+    B, D = 8, 512
+    rew = LanguageReward(None, D, 1024, 768)
+    assert list(rew.state_dict().keys()) == [f"pred.{i}.{p}" for i in (0, 2, 4, 6, 8) for p in ("weight", "bias")]
+    rew.load_state_dict(_lang_state(rew))
+    rew = rew.to(DEV)
+    alle = torch.from_numpy(make_alle(B, D, "alle")).to(DEV).requires_grad_(True)
+    feats = torch.from_numpy(detgen.uniform("langfeat", (B, 768), -0.6, 0.6)).to(DEV)
+    mask = torch.ones(B)
+    mask[5] = 0.0
+    perms = torch.from_numpy(g["perms"])
+    scores = rew.batched_scores(alle, feats, perms[0:9].to(torch.int32).to(DEV))
+    e_max, _ = rel_err(scores.detach().cpu().numpy(), g["scores"])
+    print("scores max-rel", e_max)
+    assert e_max < 1e-5
+    full, m = ops.r3m_loss(alle, perms[9:15].to(torch.int32).to(DEV), 1e-5, 1e-5, 1.0, l2dist=l2dist, scores=scores, mask=mask.to(DEV),
+                           langweight=1.0)
+    ref = dict(zip([str(n) for n in g["metric_names"]], g["metric_values"]))
+    got = m.cpu().numpy()
+    for k, v in ref.items():
+        assert abs(got[ops.METRIC_SLOTS[k]] - v) <= 1e-5 * max(1.0, abs(v)), (k, got[ops.METRIC_SLOTS[k]], v)
+    rew.mark_grads_stale()
+    full.backward()
+    e_max, e_l2 = rel_err(alle.grad.cpu().numpy(), g["dalle"])
+    print(f"dalle max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+    assert e_max < 1e-4
+    P = dict(rew.named_parameters())
+    for k, p in P.items():
+        ref_n = float(g["gradnorm_" + k])
+        assert abs(float(p.grad.double().norm()) - ref_n) <= 1e-4 * max(ref_n, 1e-12), k
+    assert rel_err(P["pred.8.weight"].grad.cpu().numpy(), g["grad_pred.8.weight"])[0] < 1e-4
+    assert rel_err(P["pred.0.bias"].grad.cpu().numpy(), g["grad_pred.0.bias"])[0] < 1e-4
+    # single-call API (reference signature) agrees with the batched rows
+    e0, eg = alle.detach()[:, 0], alle.detach()[:, 1]
+    s1, info = rew(e0, eg, feats)
+    assert info == {} and rel_err(s1.cpu().numpy(), g["scores"][0])[0] < 1e-5
+
+
+def test_full_step_with_language_vs_oracle(hip):
+    """BASELINE config 3 shape of the step (langweight=1, L1=1e-5, frozen text features) on ResNet-18, B=4, vs the CPU oracle."""
+    from oracle import detgen, r3m_ref
+    from r3m_amd import R3M
+    from r3m_amd.parallel import SingleDevice
+    from r3m_amd.trainer import Trainer
+    B = 4
+    m = R3M("cuda", 1e-4, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()}
+    m.convnet.load_state_dict(sd)
+    lsd = _lang_state(m.lang_rew)
+    m.lang_rew.load_state_dict(lsd)
+    ref = r3m_ref.R3MRef(size=18, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0)
+    ref.convnet.load_state_dict(sd)
+    ref.lang_rew.load_state_dict(lsd)
+    model = SingleDevice(m).to(DEV)
+    frames = torch.from_numpy(detgen.frames("langstep", (B, 5, 3, 224, 224)))
+    feats = torch.from_numpy(detgen.uniform("langfeat", (B, 768), -0.6, 0.6))
+    mask = torch.tensor([1.0, 1.0, 0.0, 1.0])
+    torch.manual_seed(5)
+    lang_perm = torch.stack([torch.randperm(B) for _ in range(9)])
+    tcn_perm = torch.stack([torch.randperm(B) for _ in range(6)])
+    torch.manual_seed(5)
+    metrics, _ = Trainer(1).update(model, (frames.to(DEV), (feats.to(DEV), mask)), 0)
+    mref = r3m_ref.train_step_ref(ref, frames, tcn_perm=tcn_perm, lang_feats=feats, lang_mask=mask, lang_perm=lang_perm)
+    assert set(metrics.keys()) == set(mref.keys())
+    for k, v in mref.items():
+        assert abs(metrics[k] - v) <= 2e-4 * max(1.0, abs(v)), (k, metrics[k], v)
+    # post-step language-head weights (Adam moved them by ~lr each)
+    w_gpu = m.lang_rew.state_dict()["pred.8.weight"].cpu()
+    w_ref = ref.lang_rew.state_dict()["pred.8.weight"]
+    d = (w_gpu - w_ref).abs()
+    assert float(d.max()) <= 2.1e-4 and float((d > 2e-5).float().mean()) < 0.05

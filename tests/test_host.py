@@ -1,0 +1,116 @@
+"""not gpu: host-side logic of the drop-in surface — config resolver, cleanup_config, load_r3m contract, state-dict key set
+and flat-buffer views of the encoder module, loud failure on CPU tensors, deterministic generator."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_defaults_and_overrides():
+    from r3m_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "r3m_amd", "cfgs", "config_rep.yaml"))
+    # reference defaults: r3m/cfgs/config_rep.yaml:8-41
+    assert cfg.batch_size == 32 and cfg.train_steps == 2000000 and cfg.eval_freq == 20000 and cfg.seed == 1
+    assert cfg.lr == pytest.approx(1e-4) and isinstance(cfg.lr, float)
+    assert cfg.agent.lr == cfg.lr and cfg.agent.bs == 32 and cfg.agent.device == "cuda"      # ${...} interpolation
+    assert cfg.agent.size == 34 and cfg.agent.l2dist is True and cfg.agent.tcnweight == 1.0 and cfg.agent.langweight == 0.0
+    assert cfg.agent.l1weight == pytest.approx(1e-5) and cfg.agent["_target_"] == "r3m.R3M"
+    cfg = load_config(os.path.join(ROOT, "r3m_amd", "cfgs", "config_rep.yaml"), ["batch_size=16", "agent.size=50", "lr=3e-4",
+                                                                                 "doaug=rctraj", "agent.langweight=1.0"])
+    assert cfg.agent.bs == 16 and cfg.agent.size == 50 and cfg.agent.lr == pytest.approx(3e-4) and cfg.doaug == "rctraj"
+
+
+def test_cleanup_config_and_language_head_removal():
+    import r3m_amd
+    from r3m_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "r3m_amd", "cfgs", "config_rep.yaml"), ["agent.langweight=1.0", "agent.size=18"])
+    cfg.agent["extra_key"] = 3
+    clean = r3m_amd.cleanup_config(cfg)
+    assert set(clean.keys()) <= set(r3m_amd.VALID_ARGS) and "extra_key" not in clean
+    assert clean["langweight"] == 0 and clean["_target_"] == "r3m.R3M"
+    assert "extra_key" in cfg.agent                      # input untouched (deepcopy), like the reference
+    sd = {"module.convnet.conv1.weight": 1, "module.lang_rew.pred.0.weight": 2, "module.lang_enc.model.x": 3}
+    assert list(r3m_amd.remove_language_head(sd).keys()) == ["module.convnet.conv1.weight"]
+
+
+def test_load_r3m_contract(tmp_path, monkeypatch):
+    import r3m_amd
+    with pytest.raises(NameError, match="Invalid Model ID"):
+        r3m_amd.load_r3m("resnet101")
+    monkeypatch.setenv("HOME", str(tmp_path))
+    with pytest.warns(RuntimeWarning):
+        rep = r3m_amd.load_r3m("resnet18")
+    assert hasattr(rep, "module") and isinstance(rep.module, r3m_amd.R3M)
+    assert rep.module.langweight == 0 and rep.module.outdim == 512 and rep.module.size == 18
+    keys = list(rep.state_dict().keys())
+    assert len(keys) == 120 and all(k.startswith("module.convnet.") for k in keys)
+    # a checkpoint saved in the reference layout round-trips (train_representation.py:123-138 / __init__.py:73-74)
+    d = tmp_path / ".r3m" / "r3m_18"
+    d.mkdir(parents=True)
+    sd = {k: torch.full_like(v, 0.25) if v.dtype.is_floating_point else v for k, v in rep.state_dict().items()}
+    sd["module.lang_rew.pred.0.weight"] = torch.zeros(3)
+    torch.save({"r3m": sd}, d / "model.pt")
+    (d / "config.yaml").write_text(open(os.path.join(ROOT, "r3m_amd", "cfgs", "config_rep.yaml")).read().replace("size: 34", "size: 18"))
+    rep2 = r3m_amd.load_r3m("resnet18")
+    assert float(rep2.module.convnet.conv1.weight.mean()) == 0.25
+    import r3m
+    assert r3m.load_r3m is r3m_amd.load_r3m and r3m.R3M is r3m_amd.R3M
+
+
+@pytest.mark.parametrize("size,nkeys,nparams", [(18, 120, 11176512), (34, 216, 21284672), (50, 318, 23508032)])
+def test_state_dict_matches_torchvision_layout(size, nkeys, nparams):
+    from oracle import resnet_ref
+    from r3m_amd.encoder import HipResNet
+    enc = HipResNet(size)
+    ref = {18: resnet_ref.resnet18, 34: resnet_ref.resnet34, 50: resnet_ref.resnet50}[size]()
+    ref.fc = torch.nn.Identity()
+    sd, rsd = enc.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(rsd.keys()) and len(sd) == nkeys
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(rsd[k].shape) and sd[k].dtype == rsd[k].dtype, k
+    assert sum(p.numel() for p in enc.parameters()) == nparams
+    assert [n for n, _ in enc.named_parameters()] == [n for n, _ in ref.named_parameters()]
+    # every tensor is a view of the flat buffers; conv weights are physically OHWI
+    assert enc._is_flat()
+    w = enc.layer1[0].conv1.weight if False else dict(enc.named_parameters())["layer1.0.conv1.weight"]
+    assert w.permute(0, 2, 3, 1).is_contiguous()
+    # load_state_dict from an OIHW-contiguous reference checkpoint keeps the views and the values
+    enc.load_state_dict(rsd)
+    assert enc._is_flat()
+    assert torch.equal(dict(enc.named_parameters())["layer1.0.conv1.weight"], rsd["layer1.0.conv1.weight"])
+    # deepcopy / .to() re-flatten
+    enc2 = copy.deepcopy(enc)
+    enc2._ensure()
+    assert enc2._is_flat() and enc2.flat_params().data_ptr() != enc.flat_params().data_ptr()
+    assert torch.equal(enc2.state_dict()["layer1.0.conv1.weight"], rsd["layer1.0.conv1.weight"])
+    enc2 = enc2.to(torch.device("cpu"))
+    assert enc2._is_flat()
+
+
+def test_no_cpu_fallback():
+    from r3m_amd import R3M
+    m = R3M("cpu", 1e-4, 1024, size=18, langweight=0.0, tcnweight=1.0)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(2, 3, 224, 224))
+    with pytest.raises(ValueError):
+        R3M("cpu", 1e-4, 1024, size=0)
+    for attr in ("l2weight", "l1weight", "tcnweight", "langweight", "l2dist", "size", "num_negatives", "outdim", "encoder_opt"):
+        assert hasattr(m, attr)
+    assert m.num_negatives == 3 and m.convnet.training
+
+
+def test_detgen_is_stable():
+    from oracle import detgen
+    a = detgen.uniform("x", (5,), -1, 1)
+    np.testing.assert_allclose(a, detgen.uniform("x", (5,), -1, 1))
+    assert a.dtype == np.float32 and np.all(np.abs(a) <= 1)
+    f = detgen.frames("f", (1000,))
+    assert f.min() >= 0 and f.max() <= 255 and np.all(f == np.floor(f))
+    p = detgen.permutation("p", 17)
+    assert sorted(p.tolist()) == list(range(17))
+    # pinned values: the generator must never drift (golden inputs are regenerated from it on the GPU box)
+    np.testing.assert_allclose(detgen.unit("pin", 3), [0.2076382040977478, 0.2765554189682007, 0.4500434398651123], rtol=0, atol=1e-7)

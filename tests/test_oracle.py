@@ -1,0 +1,91 @@
+"""not gpu: the CPU oracle (oracle/r3m_ref.py + oracle/resnet_ref.py) against the golden vectors produced by the
+REFERENCE's own code (tests/golden/make_golden.py, by-path import). This is what pins the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_err
+
+
+def _ref_model(size, **kw):
+    from oracle import detgen, r3m_ref
+    m = r3m_ref.R3MRef(size=size, **kw)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()})
+    return m
+
+
+@pytest.mark.parametrize("size", [18, 50])
+def test_oracle_encoder_matches_reference_golden(golden_dir, size):
+    from oracle import detgen
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, f"encoder_r{size}.npz"))
+    m = _ref_model(size, langweight=0.0, tcnweight=1.0)
+    assert sum(p.numel() for p in m.convnet.parameters()) == {18: 11176512, 50: 23508032}[size]
+    x = torch.from_numpy(detgen.frames("frames8", (8, 3, 224, 224)))
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(x).numpy(), g["h_eval"])[0] < 1e-5
+    m.train()
+    h = m(x)
+    assert rel_err(h.detach().numpy(), g["h_train"])[0] < 1e-5
+    if size == 18:
+        cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5))
+        (h * cw).sum().backward()
+        P = dict(m.convnet.named_parameters())
+        for name, ref in zip(g["grad_names"], g["grad_norms"]):
+            assert abs(float(P[str(name)].grad.double().norm()) - ref) <= 1e-3 * ref
+        assert rel_err(P["conv1.weight"].grad.numpy(), g["grad_conv1.weight"])[1] < 1e-3
+
+
+@pytest.mark.parametrize("l2dist", [True, False])
+def test_oracle_loss_matches_reference_golden(golden_dir, l2dist):
+    from oracle import detgen, r3m_ref
+    sys.path.insert(0, golden_dir)
+    from make_golden import make_alle
+    g = np.load(os.path.join(golden_dir, f"loss_{'l2' if l2dist else 'cos'}.npz"))
+    B, D = 8, 512
+    m = r3m_ref.R3MRef(size=18, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0, l2dist=l2dist)
+    sd = {}
+    for k, v in m.lang_rew.state_dict().items():
+        fan_in = v.shape[1] if v.dim() == 2 else m.lang_rew.state_dict()[k.replace("bias", "weight")].shape[1]
+        a = 1.0 / np.sqrt(fan_in)
+        sd[k] = torch.from_numpy(detgen.uniform("lr" + k, tuple(v.shape), -a, a))
+    m.lang_rew.load_state_dict(sd)
+    alle = torch.from_numpy(make_alle(B, D, "alle")).requires_grad_(True)
+    feats = torch.from_numpy(detgen.uniform("langfeat", (B, 768), -0.6, 0.6))
+    mask = torch.ones(B)
+    mask[5] = 0.0
+    perms = torch.from_numpy(g["perms"])
+    full, met, scores = r3m_ref.r3m_loss_ref(m, alle, tcn_perm=perms[9:15], lang_feats=feats, lang_mask=mask, lang_perm=perms[0:9])
+    full.backward()
+    ref = dict(zip([str(n) for n in g["metric_names"]], g["metric_values"]))
+    assert set(met.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert abs(met[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, met[k], v)
+    assert rel_err(scores.detach().numpy(), g["scores"])[0] < 1e-5
+    assert rel_err(alle.grad.numpy(), g["dalle"])[0] < 1e-4
+    assert rel_err(m.lang_rew.pred[8].weight.grad.numpy(), g["grad_pred.8.weight"])[0] < 1e-4
+    for k, p in m.lang_rew.named_parameters():
+        ref_n = float(g["gradnorm_" + k])
+        assert abs(float(p.grad.double().norm()) - ref_n) <= 1e-4 * max(ref_n, 1e-12), k
+
+
+def test_oracle_full_step_matches_reference_golden(golden_dir):
+    from oracle import detgen, r3m_ref
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "step_r18.npz"))
+    m = _ref_model(18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    frames = torch.from_numpy(detgen.frames("stepframes", (2, 5, 3, 224, 224)))
+    names = [str(n) for n in g["metric_names"]]
+    for s in range(2):
+        met = r3m_ref.train_step_ref(m, frames, tcn_perm=torch.from_numpy(g[f"perms_{s}"]))
+        assert list(met.keys()) == names
+        for k, v in zip(names, g[f"metric_values_{s}"]):
+            assert abs(met[k] - v) <= 1e-4 * max(1.0, abs(v)), (s, k, met[k], v)
+    sd = m.convnet.state_dict()
+    assert rel_err(sd["bn1.running_var"].numpy(), g["post_bn1.running_var"])[0] < 1e-5
+    assert np.abs(sd["bn1.weight"].numpy() - g["post_bn1.weight"]).max() < 4.2e-4
