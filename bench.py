@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=50)
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="clips per GPU (5 frames each); BASELINE bs=256")
+    ap.add_argument("--langweight", type=float, default=0.0, help="> 0: BASELINE configs[2] (language head on frozen text features)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
@@ -99,12 +100,16 @@ def main():
 
     torch.manual_seed(1)                               # config_rep.yaml seed
     B = args.clips_per_gpu
-    model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0, l2dist=True, bs=B)
+    model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=args.langweight, tcnweight=1.0,
+                l2dist=True, bs=B)
     model = model.to(dev)
     net = make_network_wrapper(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
     langs = [""] * B
+    if args.langweight > 0:   # frozen DistilBERT stand-in: [B,768] N(0,1)*0.3, all clips have language
+        gl = torch.Generator(device=dev).manual_seed(4321 + rank)
+        langs = torch.randn((B, 768), generator=gl, device=dev) * 0.3
     trainer = Trainer(eval_freq=10 ** 9)
 
     def barrier():
@@ -157,7 +162,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), fp32, "
-                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight=0 l1=l2=1e-5 l2dist",
+                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist",
                        "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
                        "final_full_loss": metrics["full_loss"]},
             "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -3,6 +3,7 @@
 #include "../../include/r3m_hip.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,7 +19,20 @@ void set_last_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// R3M_TRACE=1: name every launch on stderr and synchronise after it (localises a faulting kernel; debugging only)
+static int trace_mode() {
+  static int t = -1;
+  if (t < 0) { const char* e = getenv("R3M_TRACE"); t = (e && *e && *e != '0') ? 1 : 0; }
+  return t;
+}
+
 int check_launch(const char* what) {
+  if (trace_mode()) {
+    fprintf(stderr, "[r3m] %s\n", what);
+    fflush(stderr);
+    hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) { set_last_error("%s: %s (at sync)", what, hipGetErrorString(se)); return (int)se; }
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_last_error("%s: %s", what, hipGetErrorString(e));

@@ -115,23 +115,26 @@ __global__ void sum_kernel(const float* __restrict__ v, float* __restrict__ out,
   }
 }
 
-// dalle[i,f,:] += sum over every row of dX that was gathered from alle[i,f,:]
+// dalle[i,f,:] += sum over every row of dX that was gathered from alle[i,f,:]   (fixed order q = 0..14)
 __global__ __launch_bounds__(256) void lang_scatter_kernel(const float* __restrict__ dX, const int* __restrict__ iperm,
                                                             float* __restrict__ dalle, int B, int D, int LD) {
   const int i = blockIdx.x, f = blockIdx.y;
-  const int K1 = 2 * D + LD;
-  const float* src[16];
-  int n = 0;
-  for (int q = 0; q < 15; ++q) {
-    const int row = q < 6 ? i : iperm[(q - 6) * B + i];
-    const float* x = dX + ((long long)q * B + row) * K1;
-    if (f == 0) src[n++] = x;                         // first image of every call is e0
-    if (lang_bframe(q) == f) src[n++] = x + D;        // second image
+  const long long K1 = 2LL * D + LD;
+  __shared__ int rows[15];
+  if (threadIdx.x < 15) {
+    const int q = threadIdx.x;
+    rows[q] = q < 6 ? i : iperm[(q - 6) * B + i];
   }
+  __syncthreads();
   float* out = dalle + ((long long)i * 5 + f) * D;
   for (int d = threadIdx.x * 4; d < D; d += 1024) {
     f32x4 g = ld4g(out + d);
-    for (int t = 0; t < n; ++t) g += ld4g(src[t] + d);
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+      const float* x = dX + ((long long)q * B + rows[q]) * K1;
+      if (f == 0) g += ld4g(x + d);                        // first image of every call is e0
+      if (lang_bframe(q) == f) g += ld4g(x + D + d);       // second image
+    }
     *reinterpret_cast<f32x4*>(out + d) = g;
   }
 }

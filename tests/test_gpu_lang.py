@@ -103,3 +103,71 @@ def test_full_step_with_language_vs_oracle(hip):
     w_ref = ref.lang_rew.state_dict()["pred.8.weight"]
     d = (w_gpu - w_ref).abs()
     assert float(d.max()) <= 2.1e-4 and float((d > 2e-5).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("B,D,H,LD", [(4, 64, 64, 32), (5, 512, 128, 768), (3, 2048, 1024, 768)])
+def test_langrew_c_abi_vs_torch(hip, B, D, H, LD):
+    """r3m_langrew_forward/backward through the C ABI vs a torch-CPU MLP evaluated call by call (models_language.py:43-55)."""
+    import torch.nn as nn
+    from util import rnd
+    K1 = 2 * D + LD
+    layers = [nn.Linear(K1, H), nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, 1)]
+    torch.manual_seed(0)
+    for l in layers:
+        nn.init.uniform_(l.weight, -1.0 / np.sqrt(l.in_features), 1.0 / np.sqrt(l.in_features))
+        nn.init.uniform_(l.bias, -0.1, 0.1)
+    alle = torch.relu(rnd((B, 5, D), 1, -0.5, 1.0)).requires_grad_(True)
+    feats = rnd((B, LD), 2, -0.6, 0.6)
+    g = torch.Generator().manual_seed(3)
+    perm = torch.stack([torch.randperm(B, generator=g) for _ in range(9)])
+    dscore = rnd((15, B), 4, -1.0, 1.0)
+
+    def G(a, b):
+        x = torch.cat([a, b, feats], -1)
+        for l in layers[:-1]:
+            x = torch.relu(l(x))
+        return layers[-1](x).squeeze(-1)
+
+    e0, eg, es0, es1, es2 = [alle[:, i] for i in range(5)]
+    sc = [G(e0, eg), G(e0, es1), G(e0, es2), G(e0, e0), G(e0, es0), G(e0, es1)]
+    for k in range(3):
+        for j, other in enumerate((eg, es1, es2)):
+            p = perm[3 * k + j]
+            sc.append(G(e0[p], other[p]))
+    scores_ref = torch.stack(sc)
+    (scores_ref * dscore).sum().backward()
+
+    flat = torch.cat([t.detach().reshape(-1) for l in layers for t in (l.weight, l.bias)])
+    n = hip.r3m_langrew_num_params(D, H, LD)
+    assert n == flat.numel()
+    flat = torch.cat([flat, torch.zeros((-n) % 4)]).to(DEV)
+    grads = torch.zeros_like(flat)
+    wsb = hip.r3m_langrew_workspace_bytes(B, D, H, LD)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    alled, featsd = alle.detach().to(DEV), feats.to(DEV)
+    permd = perm.to(torch.int32).to(DEV)
+    from r3m_amd.ops import inverse_permutations
+    ipermd = inverse_permutations(permd).contiguous()
+    assert ipermd.dtype == torch.int32 and int(ipermd.min()) == 0 and int(ipermd.max()) == B - 1
+    scores = torch.empty((15, B), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = hip.r3m_langrew_forward(alled.data_ptr(), featsd.data_ptr(), permd.data_ptr(), flat.data_ptr(), scores.data_ptr(),
+                                 ws.data_ptr(), wsb, B, D, H, LD, st)
+    assert rc == 0, hip.r3m_last_error()
+    assert rel_err(scores.cpu().numpy(), scores_ref.detach().numpy())[0] < 2e-5
+    dalle = torch.zeros((B, 5, D), device=DEV)
+    dsd = dscore.to(DEV)
+    rc = hip.r3m_langrew_backward(dsd.data_ptr(), ipermd.data_ptr(), flat.data_ptr(), grads.data_ptr(), dalle.data_ptr(), ws.data_ptr(),
+                                  wsb, B, D, H, LD, 0, st)
+    assert rc == 0, hip.r3m_last_error()
+    torch.cuda.synchronize()
+    assert rel_err(dalle.cpu().numpy(), alle.grad.numpy())[0] < 1e-4
+    gref = torch.cat([t.grad.reshape(-1) for l in layers for t in (l.weight, l.bias)])
+    off = 0
+    for l in layers:
+        for t in (l.weight, l.bias):
+            k = t.numel()
+            e = rel_err(grads[off:off + k].cpu().numpy(), t.grad.reshape(-1).numpy())[0]
+            assert e < 1e-4, (tuple(t.shape), e)
+            off += k
+    assert gref.numel() == n
