@@ -99,6 +99,13 @@ int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream
 int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu,
                    r3m_stream_t stream);
 
+/* RandomResizedCrop resample of the rc / rctraj augmentations (r3m/utils/data_loaders.py:47-50,81-102): crop box
+ * boxes[n / frames_per_box] = {top, left, height, width} (host-drawn), bilinear resize to Ho x Wo (align_corners=False),
+ * on x/255, result * 255. frames: [N,C,Hi,Wi] uint8 or float in 0..255; out: [N,C,Ho,Wo] float. frames_per_box = 5 for
+ * rctraj (one box per clip), 1 for rc. */
+int r3m_crop_resize(const void* frames, int frames_are_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi,
+                    int Ho, int Wo, int frames_per_box, r3m_stream_t stream);
+
 /* LanguageReward, all 15 evaluations of a step batched (r3m/trainer.py:72-92 calling r3m/models/models_r3m.py:78-81 and
  * r3m/models/models_language.py:43-55). alle [B,5,D]; feats [B,lang_dim] = frozen sentence features (LangEncoder output,
  * NOT permuted); perm/iperm [9][B] int32 = the reference's torch.randperm draws in order (a,b,c) x 3 (trainer.py:86-92) and

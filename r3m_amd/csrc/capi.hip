@@ -100,6 +100,9 @@ int launch_loss_finalize(float* ws, int B, int have_lang, float* metrics, float 
                          hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                 long long step, float grad_scale, hipStream_t s);
+// augment.hip
+int launch_crop_resize(const void* in, int in_is_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,
+                       int Wo, int frames_per_box, hipStream_t s);
 // lang.hip
 long long langrew_num_params(int D, int H, int LD);
 size_t langrew_ws_floats(int B, int D, int H, int LD);
@@ -264,6 +267,12 @@ int r3m_langrew_backward(const float* dscore, const int* iperm, const float* par
   R3M_REQUIRE(dscore && iperm && params && grads && ws, "langrew_backward: null argument");
   R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_backward: workspace too small");
   return langrew_backward(dscore, iperm, params, grads, dalle, static_cast<float*>(ws), B, D, hidden, lang_dim, accumulate, S(stream));
+}
+
+int r3m_crop_resize(const void* frames, int frames_are_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,
+                    int Wo, int frames_per_box, r3m_stream_t stream) {
+  R3M_REQUIRE(frames && boxes && out, "crop_resize: null argument");
+  return launch_crop_resize(frames, frames_are_u8, boxes, out, N, C, Hi, Wi, Ho, Wo, frames_per_box, S(stream));
 }
 
 size_t r3m_loss_workspace_bytes(int B) { return loss_workspace_floats(B) * 4; }
