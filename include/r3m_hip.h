@@ -27,6 +27,7 @@ const char* r3m_last_error(void);
  * bracketed by HIP events on its own stream. Classes: 0 gather-GEMM 128x128 tile (conv fwd/dgrad, Linear), 1 gather-GEMM
  * 256x64 tile (64-channel layers), 2 wgrad 128x128, 3 wgrad 64x64. collect() sums elapsed ms / launches / algorithmic
  * FLOPs per class since the last collect (arrays of 4) and resets. */
+int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm128x128, gemm128x128 8-wave, gemm256x64, wgrad128} */
 void r3m_profile_enable(int on);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
 int r3m_profile_dump_to(const char* host_path);   /* also write one CSV row per launch at collect(); NULL/"" stops */

@@ -22,6 +22,7 @@ c_d = C.c_double
 SIGNATURES = {
     "r3m_abi_version": (c_i, []),
     "r3m_last_error": (C.c_char_p, []),
+    "r3m_debug_occupancy": (c_i, [C.POINTER(c_i)]),
     "r3m_profile_enable": (None, [c_i]),
     "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
     "r3m_profile_dump_to": (c_i, [C.c_char_p]),

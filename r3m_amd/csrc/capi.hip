@@ -67,6 +67,7 @@ void prof_end(hipStream_t s) {
   g_prof_open = false;
 }
 
+int debug_occupancy(int* out4);
 // engine.hip
 struct Plan;
 Plan* plan_create(int size, int F);
@@ -122,6 +123,7 @@ extern "C" {
 
 int r3m_abi_version(void) { return 1; }
 
+int r3m_debug_occupancy(int* out4) { return debug_occupancy(out4); }
 void r3m_profile_enable(int on) { g_prof_on = on != 0; if (!on) g_prof_used = 0; }
 // optional: every launch since the last collect as CSV rows (class,M,N,K,taps,ms,gflop) into a host file
 static FILE* g_prof_dump = nullptr;

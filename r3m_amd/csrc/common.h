@@ -55,9 +55,11 @@ struct GatherGemmParams {
   int ntaps;           // taps visited by this launch
   int flags;
   int simple_rows;     // 1: 1x1 / stride 1 / no padding -> input row offset = m*Ci (no pixel decode)
+  int debug;           // timing probes (R3M_GG_DEBUG), 0 in production
   signed char dy[MAX_TAPS];
   signed char dx[MAX_TAPS];
   unsigned char wt[MAX_TAPS];
+  int tap[MAX_TAPS];   // packed by the launcher: (dy & 255) | (dx & 255) << 8 | wt << 16  (dword table -> scalar loads)
 };
 
 struct WgradParams {

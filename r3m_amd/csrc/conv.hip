@@ -6,18 +6,28 @@
 // 1x1 / 3x3 / 7x7 convolution of ResNet-18/34/50, plus nn.Linear of the language
 // reward head (/root/reference/r3m/models/models_language.py:43-51), which is the same GEMM with a bias epilogue.
 //
-//   * gather_gemm_kernel : out[m, n] = sum_{tap, c} in[pix(m) + off(tap), c] * W[n, tap, c]
+//   * gather-GEMM : out[m, n] = sum_{tap, c} in[pix(m) + off(tap), c] * W[n, tap, c]
 //       forward conv (taps = kh,kw; input stride = conv stride), dgrad (taps flipped; stride-2 dgrad is run as
 //       4 output-parity classes so no MFMA work is spent on structural zeros), Linear (1 tap).
 //       Epilogues: raw store (+ BatchNorm sum / sum-of-squares partials), accumulate, masked residual-gradient add,
-//       bias (+ReLU).
-//   * wgrad_kernel       : dW[co, tap, ci] = sum_m dY[m, co] * in[pix(m) + off(tap), ci]   (split-K over m)
+//       bias (+ReLU), ReLU-mask.  Two staging schemes:
+//         gather_gemm_glds_kernel (128x128 tiles): global -> LDS directly (global_load_lds_dwordx4), XOR-swizzled tiles
+//         gather_gemm_kernel      (256x64 tiles, fallback): global -> VGPR -> LDS, 36-float padded rows
+//   * wgrad_kernel : dW[co, tap, ci] = sum_m dY[m, co] * in[pix(m) + off(tap), ci]   (split-K over m)
+//
+// All staging is branch-free: taps that fall outside the image and rows past the end read a valid dummy address (a
+// zero line / a clamped pixel) instead of being skipped, so the loader is straight-line code the compiler can interleave
+// with the MFMA stream; the tap table is a dword array in the kernarg segment (scalar loads).
 #include "common.h"
 #include <cstdlib>
 
 namespace r3m {
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// zeros: the source of every out-of-image / out-of-range staging load of the direct-to-LDS kernels. Sized so that a
+// lane can keep walking its channel chunks (up to Ci = 2048 floats) along it like along a real pixel row.
+__device__ __attribute__((aligned(128))) float g_zero_line[2048 + 64];
 
 // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only). Remap so that
 // each XCD walks a contiguous range of logical tiles: tiles that share an operand panel then share one L2.
@@ -29,141 +39,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// =====================================================================================================
-// gather-GEMM: block tile BM x BN, K step 32, 4 waves laid out WM x WN, each wave (BM/WM) x (BN/WN) as
-// 32x32 MFMA tiles. Operand tiles live in LDS as [row][k] with a 36-float row stride: each lane fetches
-// its fragment with one ds_read_b128 (4 consecutive k); lane half h = lane>>5 takes k = 8g+4h..8g+4h+3, so MFMA
-// step j of group g contracts k = {8g+j, 8g+4+j}. A and B use the same k permutation, the sum is unchanged.
-// The 36-float stride makes both the b128 fragment reads and the b128 staging writes bank-conflict free.
-// =====================================================================================================
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams p) {
-  constexpr int S = 36;
+// ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
+// Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
+// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
+// compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
+template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS>
+__device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                            int m0, int n0, int mt) {
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
-  constexpr int AJ = BM / 32;  // float4 staging loads per thread (A)
-  constexpr int BJ = BN / 32;  // float4 staging loads per thread (B)
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * S];
-  float* sA = smem;
-  float* sB = smem + BM * S;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int gridN = (p.Nc + BN - 1) / BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = lid / gridN, nt = lid % gridN;  // column tiles of one row panel are neighbours -> same XCD L2
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  const int c4 = tid & 7;   // which float4 of the 32-float k slice
-  const int r0 = tid >> 3;  // staging row (0..31), + 32*j
-
-  // ---- per-thread row descriptors (fixed for the whole K loop) ----
-  long long abase[AJ];
-  int aiy[AJ], aix[AJ];
-  bool aval[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + r0 + 32 * j;
-    aval[j] = m < p.M;
-    abase[j] = 0; aiy[j] = 0; aix[j] = 0;
-    if (aval[j]) {
-      if (p.simple_rows) {
-        abase[j] = (long long)m * p.Ci;
-      } else {
-        const int hw = p.Hg * p.Wg;
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int gy = rem / p.Wg;
-        const int gx = rem - gy * p.Wg;
-        abase[j] = (long long)n * p.Hi * p.Wi * p.Ci;
-        aiy[j] = gy * p.is;
-        aix[j] = gx * p.is;
-      }
-    }
-  }
-  long long bbase[BJ];
-  bool bval[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int n = n0 + r0 + 32 * j;
-    bval[j] = n < p.Nc;
-    bbase[j] = (long long)n * p.T * p.Ci;
-  }
-
-  const int kpt = p.Ci >> 5;          // K tiles per tap
-  const int nk = p.ntaps * kpt;
-
-  f32x4 ra[AJ], rb[BJ];
-  auto load_tile = [&](int kt) {
-    const int ti = kt / kpt;
-    const int c0 = (kt - ti * kpt) * 32 + c4 * 4;
-    const int dy = p.dy[ti], dx = p.dx[ti];
-    const long long woff = (long long)p.wt[ti] * p.Ci + c0;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (aval[j]) {
-        if (p.simple_rows) {
-          v = ldg4(p.A + abase[j] + c0);
-        } else {
-          const int iy = aiy[j] + dy, ix = aix[j] + dx;
-          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            v = ldg4(p.A + abase[j] + ((long long)iy * p.Wi + ix) * p.Ci + c0);
-        }
-      }
-      ra[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bval[j]) v = ldg4(p.B + bbase[j] + woff);
-      rb[j] = v;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
   const int lrow = lane & 31;
-  const int lh4 = (lane >> 5) * 4;
-  const float* fragA = sA + (wm * TM * 32 + lrow) * S + lh4;
-  const float* fragB = sB + (wn * TN * 32 + lrow) * S + lh4;
 
-  if (nk > 0) load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    // registers -> LDS (single LDS stage; the next tile's global loads fly during the MFMA phase below)
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(sA + (r0 + 32 * j) * S + c4 * 4) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (r0 + 32 * j) * S + c4 * 4) = rb[j];
-    __syncthreads();
-    if (kt + 1 < nk) load_tile(kt + 1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(fragA + t * 32 * S + g * 8);
-#pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(fragB + t * 32 * S + g * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // ---- BatchNorm statistic partials straight from the accumulators ----
   if (EPI & EPI_STATS) {
     // rows >= M were staged as zeros -> their accumulators are exactly 0 and add nothing to either sum
     float* red = smem;  // [WM][2][BN]; the K loop ended with a barrier, the tiles are dead
@@ -203,13 +93,11 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     __syncthreads();
   }
 
-  // ---- output: each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store
-  // instruction writes 4 rows x 256 contiguous bytes (dwordx4 per lane) instead of 2 rows x 128 B of single dwords ----
   constexpr int CW = TN * 32;          // columns owned by the wave
   constexpr int CS = CW + 4;           // padded slab row stride (floats)
   constexpr int F4 = CW / 4;           // float4 per slab row
   constexpr int RPI = 64 / F4;         // rows covered per store instruction
-  static_assert(4 * 32 * CS <= (BM + BN) * S, "epilogue slab must fit in the operand tiles' LDS");
+  static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
   float* slab = smem + wave * 32 * CS;
   const bool out_simple = (p.os == 1);
   const int hwg = p.Hg * p.Wg;
@@ -266,34 +154,475 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
   }
 }
 
+// per-thread descriptor of one staged A row: image base offset + top-left input pixel of the GEMM row
+struct RowDesc {
+  long long base;
+  int iy, ix;
+};
+
+__device__ __forceinline__ RowDesc decode_row(const GatherGemmParams& p, int m) {
+  RowDesc d;
+  d.base = 0; d.iy = 0; d.ix = 0;
+  if (m < p.M) {
+    if (p.simple_rows) {
+      d.base = (long long)m * p.Ci;
+    } else {
+      const int hw = p.Hg * p.Wg;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int gy = rem / p.Wg;
+      const int gx = rem - gy * p.Wg;
+      d.base = (long long)n * p.Hi * p.Wi * p.Ci;
+      d.iy = gy * p.is;
+      d.ix = gx * p.is;
+    }
+  }
+  return d;
+}
+
+// =====================================================================================================
+// gather-GEMM, direct-to-LDS staging (the 128x128 work-horse).
+// Block 128 x 128, K step 32, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of 32x32.
+// LDS: two stages of {A[128][32], B[128][32]} floats, rows of exactly 128 B (what global_load_lds needs: the 64 lanes
+// of one instruction land at base + lane*16, i.e. 8 consecutive rows), 16-byte slots XOR-swizzled by ((row>>1)&7): the
+// swizzle is applied to the per-lane GLOBAL source address and again on the fragment read, never to the LDS
+// destination. With it the ds_read_b128 fragment reads (16-lane groups, rows distinct mod 16) are conflict-free.
+// Fragments: lane half h = lane>>5 reads k = 8g+4h..+3 of group g; MFMA step j contracts k = {8g+j, 8g+4+j} — A and B use
+// the same permutation of k, the sum is unchanged.
+// Pipeline: tile t+1's DMA is issued right after the barrier that publishes tile t and lands during tile t's 64 MFMAs
+// per wave; one barrier per K step, no staging registers, no ds_write instructions.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void gather_gemm_glds_kernel(const GatherGemmParams p) {
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 2, TN = 2;
+  constexpr int STAGE = (BM + BN) * 32;                   // floats per stage (32 KiB)
+  __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;  // column tiles of one row panel are neighbours -> same XCD L2
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // staging: wave w fills rows [32w, 32w+32) of A and of B, 8 rows (1 KiB) per instruction
+  const int srow = lane >> 3;          // row within the 8-row group
+  const int pslot = lane & 7;          // physical 16-byte slot written by this lane
+  const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  RowDesc ad[4];
+  int acol[4];                         // logical k offset (floats) this lane fetches for A/B row group j
+  unsigned arow_ok = 0;
+  long long bbase[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 32 + j * 8 + srow;                 // row inside the tile
+    acol[j] = (pslot ^ ((r >> 1) & 7)) * 4;
+    const int m = m0 + r;
+    ad[j] = decode_row(p, m);
+    if (m < p.M) arow_ok |= 1u << j;
+    const int n = min(n0 + r, p.Nc - 1);                    // columns past Nc are computed on a clamped row, never stored
+    bbase[j] = (long long)n * p.T * p.Ci;
+  }
+  const float* zline = g_zero_line + pslot * 4;
+
+  const int kpt = p.Ci >> 5;          // K tiles per tap
+  const int nk = p.ntaps * kpt;
+
+  auto issue_tile = [&](int pack, int chunk, int stage) {
+    const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
+    const int c0 = chunk * 32;
+    const long long woff = (long long)wt * p.Ci + c0;
+    float* la = smem + stage * STAGE + wave * 32 * 32;
+    float* lb = la + BM * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
+      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
+      const float* src = p.A + ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci + c0 + acol[j];
+      // bitwise select keeps the loader straight-line (a ?: here is turned back into an exec-masked branch)
+      const unsigned long long msk = in ? ~0ull : 0ull;
+      src = reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(src) & msk) |
+                                           (reinterpret_cast<unsigned long long>(zline) & ~msk));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(la + j * 8 * 32), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* src = p.B + bbase[j] + woff + acol[j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lb + j * 8 * 32), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addressing: row = lrow (+32 per MFMA tile), logical slot 2g+h, physical slot = logical ^ ((row>>1)&7)
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int xr = (lrow >> 1) & 7;
+  int goff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) goff[g] = ((2 * g + lh) ^ xr) * 4;
+  const float* fragA0 = smem + (wm * 64 + lrow) * 32;
+  const float* fragB0 = smem + BM * 32 + (wn * 64 + lrow) * 32;
+
+  int tap_n = 0, chunk_n = 0;
+  int pack_cur = nk > 0 ? p.tap[0] : 0;
+  int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
+  if (nk > 0) issue_tile(pack_cur, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = (p.debug == 0) ? (kt & 1) : 0;       // timing probes read stage 0 only
+    if (p.debug != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of tile kt has landed
+    if (p.debug != 2) __syncthreads();                   // everyone's has; and everyone is done reading stage cur^1
+    if (kt + 1 < nk && p.debug != 1) {
+      if (++chunk_n == kpt) {
+        chunk_n = 0;
+        ++tap_n;
+        pack_cur = pack_next;
+        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      }
+      issue_tile(pack_cur, chunk_n, (p.debug == 0) ? (cur ^ 1) : 1);
+    }
+    const float* fa = fragA0 + cur * STAGE;
+    const float* fb = fragB0 + cur * STAGE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(fa + t * 32 * 32 + goff[g]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(fb + t * 32 * 32 + goff[g]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the stages
+
+  gg_epilogue<BM, BN, WM, WN, EPI, 2 * STAGE>(p, acc, smem, m0, n0, mt);
+}
+
+// =====================================================================================================
+// gather-GEMM, direct-to-LDS staging, low-VALU main loop (used whenever Ci/32 is even — every ResNet layer).
+// On gfx950 the f32-input MFMA runs at the fp32 VECTOR rate and, measured here, does NOT overlap with VALU work of
+// co-resident waves: every VALU instruction in the K loop costs MFMA time (loads issued but never waited for cost the
+// same 12 % as the full pipeline; removing the loader entirely gives 139-149 TF). So this variant strips the loop of
+// vector ALU work: per-lane source POINTERS are kept per staged row and advanced by 256 B every second K step, the odd
+// step uses the instruction's immediate offset (+128 B), validity is folded into the pointer once per tap (invalid rows
+// walk along a zero buffer), the K loop is unrolled by two so LDS stage and fragment offsets are immediates, and the
+// wave-uniform LDS destinations live in SGPRs. ~8 VALU instructions per K step instead of ~160.
+// =====================================================================================================
+template <int STG, int IMM>
+__device__ __forceinline__ void glds_issue(const float* const (&pa)[4], const float* const (&pb)[4], float* smem, int wave_s) {
+  constexpr int STAGE = 256 * 32;
+  // the instruction's immediate offset is added to BOTH the global address and the LDS address (M0 base + offset +
+  // lane*16), so the LDS destination is pre-biased by -IMM
+  float* la = smem + STG * STAGE + wave_s * 32 * 32 - IMM / 4;
+  float* lb = la + 128 * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
+                                     (__attribute__((address_space(3))) void*)(la + j * 8 * 32), 16, IMM, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
+                                     (__attribute__((address_space(3))) void*)(lb + j * 8 * 32), 16, IMM, 0);
+}
+
+template <int STG>
+__device__ __forceinline__ void glds_mfma(f32x16 (&acc)[2][2], const float* const (&fa)[4], const float* const (&fb)[4]) {
+  constexpr int STAGE = 256 * 32;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f32x4*>(fa[g] + STG * STAGE + t * 32 * 32);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const f32x4*>(fb[g] + STG * STAGE + t * 32 * 32);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemmParams p) {
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 2, TN = 2;
+  constexpr int STAGE = (BM + BN) * 32;
+  __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR: LDS destinations stay scalar
+  const int wm = wave_s / WN, wn = wave_s % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int srow = lane >> 3, pslot = lane & 7;
+  const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  RowDesc ad[4];
+  int acol[4];
+  unsigned arow_ok = 0;
+  const float* bptr[4];                // weight row pointers (tap 0, chunk 0)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave_s * 32 + j * 8 + srow;
+    acol[j] = (pslot ^ ((r >> 1) & 7)) * 4;
+    const int m = m0 + r;
+    ad[j] = decode_row(p, m);
+    if (m < p.M) arow_ok |= 1u << j;
+    const int n = min(n0 + r, p.Nc - 1);
+    bptr[j] = p.B + (long long)n * p.T * p.Ci + acol[j];
+  }
+
+  const int kpt = p.Ci >> 5;          // K tiles per tap (even)
+  const int hpt = kpt >> 1;           // tile pairs per tap
+  const int npairs = p.ntaps * hpt;
+
+  const float* pa[4];
+  const float* pb[4];
+  auto set_tap = [&](int pack) {
+    const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
+      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
+      const float* src = p.A + ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci + acol[j];
+      const unsigned long long msk = in ? ~0ull : 0ull;
+      pa[j] = reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(src) & msk) |
+                                             (reinterpret_cast<unsigned long long>(g_zero_line + acol[j]) & ~msk));
+      pb[j] = bptr[j] + (long long)wt * p.Ci;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int xr = (lrow >> 1) & 7;
+  const float* fa[4];
+  const float* fb[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int go = ((2 * g + lh) ^ xr) * 4;
+    fa[g] = smem + (wm * 64 + lrow) * 32 + go;
+    fb[g] = smem + BM * 32 + (wn * 64 + lrow) * 32 + go;
+  }
+
+  int tap_n = 0, cp = 0;
+  if (npairs > 0) {
+    set_tap(p.tap[0]);
+    glds_issue<0, 0>(pa, pb, smem, wave_s);                      // tile 0
+  }
+  int pack_next = p.ntaps > 1 ? p.tap[1] : 0;
+  for (int pr = 0; pr < npairs; ++pr) {
+    // ---- even tile (stage 0) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    glds_issue<1, 128>(pa, pb, smem, wave_s);                    // odd tile of the pair: same tap, next 32 channels
+    glds_mfma<0>(acc, fa, fb);
+    // ---- odd tile (stage 1) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pr + 1 < npairs) {
+      if (++cp == hpt) {
+        cp = 0;
+        ++tap_n;
+        set_tap(pack_next);
+        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += 64; pb[j] += 64; }
+      }
+      glds_issue<0, 0>(pa, pb, smem, wave_s);                    // even tile of the next pair
+    }
+    glds_mfma<1>(acc, fa, fb);
+  }
+  __syncthreads();
+
+  gg_epilogue<BM, BN, WM, WN, EPI, 2 * STAGE>(p, acc, smem, m0, n0, mt);
+}
+
+// =====================================================================================================
+// gather-GEMM, register staging (256x64 tiles for 64-channel layers; also the 128x128 fallback R3M_GG_GLDS=0).
+// Operand tiles live in LDS as [row][k] with a 36-float row stride (conflict-free b128 writes and fragment reads).
+// Single LDS stage; the next tile's global loads fly during the MFMA phase.
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherGemmParams p) {
+  constexpr int NT = WM * WN * 64;      // threads
+  constexpr int RPP = NT / 8;           // staging rows per pass (8 lanes x float4 cover one 32-float row)
+  constexpr int S = 36;
+  constexpr int STAGE = (BM + BN) * S;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int AJ = BM / RPP;  // float4 staging loads per thread (A)
+  constexpr int BJ = BN / RPP;  // float4 staging loads per thread (B)
+  __shared__ __attribute__((aligned(16))) float smem[STAGE];
+  float* sA = smem;
+  float* sB = smem + BM * S;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int c4 = tid & 7;   // which float4 of the 32-float k slice
+  const int r0 = tid >> 3;  // staging row (0..RPP-1), + RPP*j
+
+  const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  RowDesc ad[AJ];
+  unsigned arow_ok = 0;
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + r0 + RPP * j;
+    ad[j] = decode_row(p, m);
+    if (m < p.M) arow_ok |= 1u << j;
+  }
+  long long bbase[BJ];
+  unsigned brow_ok = 0;
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    int n = n0 + r0 + RPP * j;
+    if (n < p.Nc) brow_ok |= 1u << j; else n = p.Nc - 1;
+    bbase[j] = (long long)n * p.T * p.Ci;
+  }
+
+  const int kpt = p.Ci >> 5;          // K tiles per tap
+  const int nk = p.ntaps * kpt;
+
+  f32x4 ra[AJ], rb[BJ];
+  unsigned a_ok = 0;                  // validity bits of the tile currently held in ra[]
+  auto load_tile = [&](int pack, int chunk) {
+    const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
+    const int c0 = chunk * 32 + c4 * 4;
+    const long long woff = (long long)wt * p.Ci + c0;
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb);
+      ok |= (in ? 1u : 0u) << j;
+      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
+      ra[j] = ldg4(p.A + ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci + c0);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = ldg4(p.B + bbase[j] + woff);
+    a_ok = ok & arow_ok;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow = lane & 31;
+  const int lh4 = (lane >> 5) * 4;
+  const float* fragA = sA + (wm * TM * 32 + lrow) * S + lh4;
+  const float* fragB = sB + (wn * TN * 32 + lrow) * S + lh4;
+
+  int tap_n = 0, chunk_n = 0;
+  int pack_cur = nk > 0 ? p.tap[0] : 0;
+  int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
+  if (nk > 0) load_tile(pack_cur, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<f32x4*>(sA + (r0 + RPP * j) * S + c4 * 4) = ((a_ok >> j) & 1u) ? ra[j] : zero4;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<f32x4*>(sB + (r0 + RPP * j) * S + c4 * 4) = ((brow_ok >> j) & 1u) ? rb[j] : zero4;
+    __syncthreads();
+    if (kt + 1 < nk) {
+      if (++chunk_n == kpt) {
+        chunk_n = 0;
+        ++tap_n;
+        pack_cur = pack_next;
+        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      }
+      load_tile(pack_cur, chunk_n);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(fragA + t * 32 * S + g * 8);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(fragB + t * 32 * S + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  gg_epilogue<BM, BN, WM, WN, EPI, STAGE>(p, acc, smem, m0, n0, mt);
+}
+
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 int gather_gemm_grid_m(int M, int Nc) { return gg_wide(Nc) ? ceil_div(M, 128) : ceil_div(M, 256); }
 
-template <int BM, int BN, int WM, int WN>
-static int gg_dispatch_epi(const GatherGemmParams& p, int grid, hipStream_t s) {
-  const int f = p.flags;
-#define GG_CASE(E)                                                                                                   \
-  case E:                                                                                                            \
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, E>), dim3(grid), dim3(256), 0, s, p);                \
-    return 0;
-  switch (f) {
-    GG_CASE(0)
-    GG_CASE(EPI_STATS)
-    GG_CASE(EPI_ACCUM)
-    GG_CASE(EPI_MASKED_ADD)
-    GG_CASE(EPI_BIAS)
-    GG_CASE(EPI_RELU)
-    GG_CASE(EPI_BIAS | EPI_RELU)
-    GG_CASE(EPI_MASK_OUT)
-    default:
-      set_last_error("gather_gemm: unsupported epilogue flag combination %d", f);
-      return 1;
-  }
-#undef GG_CASE
+// R3M_GG_GLDS: 2 (default) low-VALU direct-to-LDS kernel, 1 generic direct-to-LDS kernel, 0 register staging
+static int gg_use_glds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_GG_GLDS"); v = e ? atoi(e) : 2; }
+  return v;
 }
 
-int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s) {
+#define GG_EPI_SWITCH(LAUNCH)                                                       \
+  switch (p.flags) {                                                                \
+    case 0: LAUNCH(0); break;                                                       \
+    case EPI_STATS: LAUNCH(EPI_STATS); break;                                       \
+    case EPI_ACCUM: LAUNCH(EPI_ACCUM); break;                                       \
+    case EPI_MASKED_ADD: LAUNCH(EPI_MASKED_ADD); break;                             \
+    case EPI_BIAS: LAUNCH(EPI_BIAS); break;                                         \
+    case EPI_RELU: LAUNCH(EPI_RELU); break;                                         \
+    case EPI_BIAS | EPI_RELU: LAUNCH(EPI_BIAS | EPI_RELU); break;                   \
+    case EPI_MASK_OUT: LAUNCH(EPI_MASK_OUT); break;                                 \
+    default:                                                                        \
+      set_last_error("gather_gemm: unsupported epilogue flag combination %d", p.flags); \
+      return 1;                                                                     \
+  }
+
+int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
+  GatherGemmParams p = p_in;
   R3M_REQUIRE(p.Ci % 32 == 0, "gather_gemm: Ci=%d must be a multiple of 32", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm: Nc=%d must be a multiple of 4", p.Nc);
   R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
@@ -301,21 +630,40 @@ int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
               "gather_gemm: operands must be 16-byte aligned");
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("R3M_GG_DEBUG"); dbg = e ? atoi(e) : 0; }
+    p.debug = dbg;   // timing probes only (wrong results when != 0)
+  }
+  for (int t = 0; t < p.ntaps; ++t)
+    p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
   // algorithmic FLOPs: the stem arrives as 160-wide patch rows of which 147 are real (7*7*3)
   const double kdim = (double)p.ntaps * (p.Ci == 160 ? 147 : p.Ci);
   const double flops = 2.0 * (double)p.M * (double)p.Nc * kdim;
-  int rc;
   if (gg_wide(p.Nc)) {
-    const int gm = ceil_div(p.M, 128), gn = ceil_div(p.Nc, 128);
+    const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = gg_dispatch_epi<128, 128, 2, 2>(p, gm * gn, s);
+    if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
+#define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_GLDS2)
+#undef LAUNCH_GLDS2
+    } else if (gg_use_glds()) {
+#define LAUNCH_GLDS(E) hipLaunchKernelGGL((gather_gemm_glds_kernel<E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_GLDS)
+#undef LAUNCH_GLDS
+    } else {
+#define LAUNCH_REG(E) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_REG)
+#undef LAUNCH_REG
+    }
   } else {
-    const int gm = ceil_div(p.M, 256), gn = ceil_div(p.Nc, 64);
+    const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = gg_dispatch_epi<256, 64, 4, 1>(p, gm * gn, s);
+#define LAUNCH_NARROW(E) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, E>), dim3(grid), dim3(256), 0, s, p)
+    GG_EPI_SWITCH(LAUNCH_NARROW)
+#undef LAUNCH_NARROW
   }
   prof_end(s);
-  if (rc) return rc;
   return check_launch("gather_gemm");
 }
 
@@ -323,6 +671,8 @@ int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s) {
 // wgrad: dW[co, tap, ci] = sum_m dY[m, co] * X[pix(m) + off(tap), ci].  GEMM M' = Co tile, N' = Ci tile,
 // K' = rows m (split over blockIdx.y). Both operands arrive row(m)-major with channels contiguous, which is exactly
 // the [k][i] LDS image the 32x32x2 MFMA wants for conflict-free ds_read_b32 fragment reads.
+// Staging is branch-free (clamped addresses + select-to-zero at the LDS write); the (n, oy, ox) decode of the rows a thread
+// stages is advanced incrementally (+32 rows per K step) instead of dividing.
 // =====================================================================================================
 template <int BMt, int BNt>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -350,35 +700,84 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int b_c = (tid % B_F4) * 4, b_r = tid / B_F4;
   const bool a_cv = (co0 + a_c) < p.Co;
   const bool b_cv = (ci0 + b_c) < p.Ci;
+  const int a_col = a_cv ? co0 + a_c : 0;
+  const int b_col = b_cv ? ci0 + b_c : 0;
   const int hw = p.Ho * p.Wo;
 
+  const int q32 = 32 / p.Wo, r32 = 32 - q32 * p.Wo;
+  const bool fast_adv = (q32 + 1) <= p.Ho;        // one conditional subtract per axis is enough
+  const long long img = (long long)p.Hi * p.Wi * p.Ci;
+  long long xb[BJ];
+  int xoy[BJ], xox[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int m = ms + b_r + j * B_RPP;
+    if (p.simple_rows) {
+      xb[j] = 0; xoy[j] = 0; xox[j] = 0;
+    } else {
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      xoy[j] = rem / p.Wo;
+      xox[j] = rem - xoy[j] * p.Wo;
+      xb[j] = (long long)n * img;
+    }
+  }
+
   f32x4 ra[AJ], rb[BJ];
+  unsigned a_ok = 0, b_ok = 0;
   auto load_tile = [&](int mk) {
+    unsigned oka = 0, okb = 0;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int m = mk + a_r + j * A_RPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < me && a_cv) v = ldg4(p.dY + (long long)m * p.Co + co0 + a_c);
-      ra[j] = v;
+      const bool ok = (m < me) && a_cv;
+      oka |= (ok ? 1u : 0u) << j;
+      const int mc = min(m, me - 1);
+      ra[j] = ldg4(p.dY + (long long)mc * p.Co + a_col);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int m = mk + b_r + j * B_RPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < me && b_cv) {
-        if (p.simple_rows) {
-          v = ldg4(p.X + (long long)m * p.Ci + ci0 + b_c);
-        } else {
+      const bool mok = (m < me) && b_cv;
+      long long off;
+      bool in = true;
+      if (p.simple_rows) {
+        off = (long long)min(m, me - 1) * p.Ci;
+      } else {
+        const int iy = xoy[j] * p.stride + kh - p.pad, ix = xox[j] * p.stride + kw - p.pad;
+        in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+        const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+        off = xb[j] + ((long long)iyc * p.Wi + ixc) * p.Ci;
+        off = (m < me) ? off : 0;       // rows past the split: any valid address, masked below
+      }
+      okb |= ((mok && in) ? 1u : 0u) << j;
+      rb[j] = ldg4(p.X + off + b_col);
+    }
+    a_ok = oka; b_ok = okb;
+    if (!p.simple_rows) {               // advance the decode to the next K step (+32 rows)
+      if (fast_adv) {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+          int ox = xox[j] + r32, oy = xoy[j] + q32;
+          const bool cx = ox >= p.Wo;
+          ox = cx ? ox - p.Wo : ox;
+          oy = cx ? oy + 1 : oy;
+          const bool cy = oy >= p.Ho;
+          oy = cy ? oy - p.Ho : oy;
+          xb[j] = cy ? xb[j] + img : xb[j];
+          xox[j] = ox; xoy[j] = oy;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+          const int m = mk + 32 + b_r + j * B_RPP;
           const int n = m / hw;
           const int rem = m - n * hw;
-          const int oy = rem / p.Wo;
-          const int ox = rem - oy * p.Wo;
-          const int iy = oy * p.stride + kh - p.pad, ix = ox * p.stride + kw - p.pad;
-          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            v = ldg4(p.X + (((long long)n * p.Hi + iy) * p.Wi + ix) * p.Ci + ci0 + b_c);
+          xoy[j] = rem / p.Wo;
+          xox[j] = rem - xoy[j] * p.Wo;
+          xb[j] = (long long)n * img;
         }
       }
-      rb[j] = v;
     }
   };
 
@@ -396,10 +795,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   if (ms < me) load_tile(ms);
   for (int mk = ms; mk < me; mk += BK) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(sA + (a_r + j * A_RPP) * BMt + a_c) = ra[j];
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<f32x4*>(sA + (a_r + j * A_RPP) * BMt + a_c) = ((a_ok >> j) & 1u) ? ra[j] : zero4;
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(sB + (b_r + j * B_RPP) * BNt + b_c) = rb[j];
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<f32x4*>(sB + (b_r + j * B_RPP) * BNt + b_c) = ((b_ok >> j) & 1u) ? rb[j] : zero4;
     __syncthreads();
     if (mk + BK < me) load_tile(mk + BK);
 #pragma unroll
@@ -431,6 +833,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         if (ci < p.Ci) out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
       }
     }
+}
+
+// debugging aid: resident blocks per CU the runtime predicts for the main kernel variants
+int debug_occupancy(int* out4) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_glds_kernel<EPI_STATS>, 256, 0) != hipSuccess) return 1;
+  out4[0] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_kernel<128, 128, 2, 2, EPI_STATS>, 256, 0) != hipSuccess) return 1;
+  out4[1] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_kernel<256, 64, 4, 1, EPI_STATS>, 256, 0) != hipSuccess) return 1;
+  out4[2] = n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<128, 128>, 256, 0) != hipSuccess) return 1;
+  out4[3] = n;
+  return 0;
 }
 
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }

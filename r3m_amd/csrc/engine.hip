@@ -11,6 +11,7 @@
 // stored OHWI (= logical OIHW tensors with channels_last strides, so state-dict interchange needs no copy kernels).
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,11 +58,18 @@ struct Plan {
   long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
   // arena offsets (floats)
   long long col_off, w160_off, dw160_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
-  long long G_off[4];
+  long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
   long long arena_floats = 0;
   long long gmax = 0;
   int last_training = 1;
   int gd = 0;             // which G buffer holds the running output-gradient between backward stages
+  // side stream: wgrad(L) runs concurrently with dgrad(L) (both only need dY_L), filling each other's tile-quantisation tails
+  hipStream_t side = nullptr;
+  hipEvent_t ev_dy = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
+  bool wg_pending[2] = {false, false};
+  int a_next = 0;         // which of A0/A1 the next dY goes to
+  int roles[5] = {0, 1, 2, 3, 4};
+  int use_side = -1;
 };
 
 static long long align64(long long x) { return (x + 63) / 64 * 64; }
@@ -181,7 +189,7 @@ Plan* plan_create(int size, int F) {
   P.wt_off = take(wmax);
   P.wgp_off = take(wgp_max);
   P.gmax = gmax;
-  for (int g = 0; g < 4; ++g) P.G_off[g] = take(gmax);
+  for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
   P.arena_floats = off;
   return Pp;
 }
@@ -404,68 +412,142 @@ static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flag
 }
 
 // Backward stages: 0 = avgpool + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem. The gradient w.r.t. the current
-// block output lives in arena buffer G[gd]; `gd` is carried across calls in *gd_io so stages can be issued one by one
-// (the data-parallel wrapper launches the RCCL all-reduce of a finished stage's gradient slice in between).
+// block output lives in one of five arena buffers (roles rotate: D = dOut, A0/A1 = dY alternating, B, C); the roles are
+// carried across calls so stages can be issued one by one (the data-parallel wrapper launches the RCCL all-reduce of a
+// finished stage's gradient slice in between).
+//
+// Streams: dgrad(L) and wgrad(L) both consume only dY_L, so wgrad runs on a side stream (event-ordered) while the main
+// stream continues with dgrad(L) -> bn_backward(L-1) -> ... . Two MFMA-bound kernels sharing the chip fill each other's
+// last-wave tails (a 128x128 conv tile runs ~0.3 ms, grids are 2.5-10 waves of tiles) and hide the small kernels between them.
+// dY alternates between A0 and A1 so wgrad(L) has until bn_backward(L-2) to finish; each stage ends with a join.
+static int side_init(Plan& P) {
+  if (P.use_side < 0) {
+    // opt-in (R3M_SIDE_STREAM=1): measured +1.7 % step throughput on ResNet-50 F=1280, but co-running kernels inflate each
+    // other's per-launch durations, which blurs the per-kernel roofline accounting of bench.py; off by default.
+    const char* e = getenv("R3M_SIDE_STREAM");
+    P.use_side = (e && *e && *e != '0') ? 1 : 0;
+  }
+  if (!P.use_side || P.side) return 0;
+  if (hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking) != hipSuccess) { set_last_error("side stream: create failed"); return 1; }
+  hipEvent_t* evs[4] = {&P.ev_dy, &P.ev_wg[0], &P.ev_wg[1], &P.ev_join};
+  for (auto ev : evs)
+    if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { set_last_error("side stream: event create failed"); return 1; }
+  return 0;
+}
+
 int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
                   int accumulate, int* gd_io, hipStream_t s) {
   Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate};
+  TRY(side_init(P));
+  const bool side_on = P.use_side && P.side;
+  Ctx cs = c;                       // context whose launches go to the side stream
+  cs.s = side_on ? P.side : s;
   const int F = P.F;
-  int gd = *gd_io;
-  auto G = [&](int i) { return arena + P.G_off[i & 3]; };
+  // buffer roles: role[0]=D, role[1]=A0, role[2]=A1, role[3]=B, role[4]=C  (indices into G_off), rotated per block
+  int* role = P.roles;
+  auto Gp = [&](int r) { return arena + P.G_off[role[r]]; };
+
+  // dY for conv L has just been produced on the main stream in A[ai]: launch its wgrad on the side stream
+  auto wgrad_async = [&](const ConvSpec& L, const float* X, const float* dY, int ai) -> int {
+    if (!side_on) return wgrad(c, L, X, dY);
+    if (hipEventRecord(P.ev_dy, s) != hipSuccess || hipStreamWaitEvent(P.side, P.ev_dy, 0) != hipSuccess) {
+      set_last_error("side stream: event ordering failed");
+      return 1;
+    }
+    TRY(wgrad(cs, L, X, dY));
+    if (hipEventRecord(P.ev_wg[ai], P.side) != hipSuccess) { set_last_error("side stream: record failed"); return 1; }
+    P.wg_pending[ai] = true;
+    return 0;
+  };
+  // before the main stream overwrites A[ai], the wgrad that last read it must be done
+  auto acquire_A = [&](int ai) -> int {
+    if (side_on && P.wg_pending[ai]) {
+      if (hipStreamWaitEvent(s, P.ev_wg[ai], 0) != hipSuccess) { set_last_error("side stream: wait failed"); return 1; }
+      P.wg_pending[ai] = false;
+    }
+    return 0;
+  };
+  auto join_side = [&]() -> int {
+    if (!side_on) return 0;
+    if (hipEventRecord(P.ev_join, P.side) != hipSuccess || hipStreamWaitEvent(s, P.ev_join, 0) != hipSuccess) {
+      set_last_error("side stream: join failed");
+      return 1;
+    }
+    P.wg_pending[0] = P.wg_pending[1] = false;
+    return 0;
+  };
+  auto next_A = [&](int* ai) -> float* {
+    *ai = P.a_next;
+    P.a_next ^= 1;
+    return Gp(1 + *ai);
+  };
+
   for (int st = stage_begin; st < stage_end; ++st) {
     const int layer = 3 - st;
     if (st == 0) {
       const BlockSpec& last = P.blocks.back();
-      gd = 0;
-      TRY(launch_avgpool_bwd(dh, G(gd), F, last.Ho * last.Wo, last.Co, s));
+      for (int r = 0; r < 5; ++r) role[r] = r;
+      P.a_next = 0;
+      P.wg_pending[0] = P.wg_pending[1] = false;
+      TRY(launch_avgpool_bwd(dh, Gp(0), F, last.Ho * last.Wo, last.Co, s));
     }
     for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
       const BlockSpec& B = P.blocks[bi];
       if (B.stage != layer) continue;
-      const float* dOut = G(gd);
+      const float* dOut = Gp(0);
       const float* Out = arena + B.out_off;
       const float* Xin = arena + B.in_off;
-      float* Ga = G(gd + 1);
-      float* Gb = G(gd + 2);
-      float* Gc = G(gd + 3);
+      float* Gb = Gp(3);
+      float* Gc = Gp(4);
       // last conv of the block: its BatchNorm output joined the residual add, mask comes from the block output
       const float* dz = dOut;
       const float* zmask = Out;
+      int ai;
       for (int j = B.nconv - 1; j >= 1; --j) {
         const ConvSpec& L = P.convs[B.conv[j]];
         const ConvSpec& Lprev = P.convs[B.conv[j - 1]];
-        TRY(bn_backward(c, L, dz, zmask, Ga));
-        TRY(wgrad(c, L, arena + Lprev.Z_off, Ga));
-        TRY(dgrad(c, L, Ga, Gb, 0, nullptr, nullptr));
-        dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward (-> Ga) before dgrad rewrites it
+        float* dY = next_A(&ai);
+        TRY(acquire_A(ai));
+        TRY(bn_backward(c, L, dz, zmask, dY));
+        TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
+        TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr));
+        dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward before a later dgrad rewrites it
       }
       const ConvSpec& L1 = P.convs[B.conv[0]];
-      TRY(bn_backward(c, L1, dz, zmask, Ga));
-      TRY(wgrad(c, L1, Xin, Ga));
+      float* dY1 = next_A(&ai);
+      TRY(acquire_A(ai));
+      TRY(bn_backward(c, L1, dz, zmask, dY1));
+      TRY(wgrad_async(L1, Xin, dY1, ai));
       if (B.ds >= 0) {
         const ConvSpec& Ld = P.convs[B.ds];
-        TRY(dgrad(c, L1, Ga, Gc, 0, nullptr, nullptr));
-        TRY(bn_backward(c, Ld, dOut, Out, Gb));
-        TRY(wgrad(c, Ld, Xin, Gb));
-        TRY(dgrad(c, Ld, Gb, Gc, EPI_ACCUM, nullptr, nullptr));
+        TRY(dgrad(c, L1, dY1, Gc, 0, nullptr, nullptr));
+        int ad;
+        float* dYd = next_A(&ad);
+        TRY(acquire_A(ad));
+        TRY(bn_backward(c, Ld, dOut, Out, dYd));
+        TRY(wgrad_async(Ld, Xin, dYd, ad));
+        TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
       } else {
-        TRY(dgrad(c, L1, Ga, Gc, EPI_MASKED_ADD, dOut, Out));
+        TRY(dgrad(c, L1, dY1, Gc, EPI_MASKED_ADD, dOut, Out));
       }
-      gd = (gd + 3) & 3;  // Gc becomes the gradient of the previous block's output
+      // C becomes the gradient of the previous block's output; the old D is free (only the main stream ever read it)
+      const int t = role[0]; role[0] = role[4]; role[4] = t;
     }
     if (st == 3) {
       // stem: maxpool -> BN+ReLU -> conv1 (no input gradient)
       const ConvSpec& L0 = P.convs[0];
-      float* Ga = G(gd + 1);
-      float* Gb = G(gd + 2);
-      TRY(launch_maxpool_bwd(G(gd), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Ga, F, 112, 112, 64, s));
-      TRY(bn_backward(c, L0, Ga, nullptr, Gb));
+      float* Gb = Gp(3);
+      float* Gc = Gp(4);
+      TRY(launch_maxpool_bwd(Gp(0), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Gb, F, 112, 112, 64, s));
+      TRY(bn_backward(c, L0, Gb, nullptr, Gc));
+      TRY(join_side());   // the stem wgrad shares the split-K scratch with the side stream's wgrads
       float* dw160 = arena + P.dw160_off;
-      TRY(conv_wgrad_launch(arena + P.col_off, Gb, dw160, arena + P.wgp_off, F * 112 * 112, 1, 1, 160, 64, 1, 1, 0, 0, s));
+      TRY(conv_wgrad_launch(arena + P.col_off, Gc, dw160, arena + P.wgp_off, F * 112 * 112, 1, 1, 160, 64, 1, 1, 0, 0, s));
       TRY(launch_unpack_stem_dw(dw160, grads + L0.w_off, accumulate, s));
     }
+    TRY(join_side());     // a finished stage's gradients are complete on the main stream (all-reduce hook, Adam)
   }
-  *gd_io = gd;
+  *gd_io = role[0];
   return 0;
 }
 
@@ -494,7 +576,14 @@ int plan_stage_range(Plan* P, int stage, long long* off, long long* count) {
   if (count) *count = e - b;
   return 0;
 }
-void plan_destroy(Plan* P) { delete P; }
+void plan_destroy(Plan* P) {
+  if (P->side) {
+    (void)hipStreamDestroy(P->side);
+    for (hipEvent_t ev : {P->ev_dy, P->ev_wg[0], P->ev_wg[1], P->ev_join})
+      if (ev) (void)hipEventDestroy(ev);
+  }
+  delete P;
+}
 int* plan_gd(Plan* P) { return &P->gd; }
 
 }  // namespace r3m
