@@ -324,26 +324,27 @@ __global__ __launch_bounds__(256) void gather_gemm_glds_kernel(const GatherGemmP
 // walk along a zero buffer), the K loop is unrolled by two so LDS stage and fragment offsets are immediates, and the
 // wave-uniform LDS destinations live in SGPRs. ~8 VALU instructions per K step instead of ~160.
 // =====================================================================================================
-template <int STG, int IMM>
-__device__ __forceinline__ void glds_issue(const float* const (&pa)[4], const float* const (&pb)[4], float* smem, int wave_s) {
-  constexpr int STAGE = 256 * 32;
+template <int BM, int BN, int STG, int IMM>
+__device__ __forceinline__ void glds_issue(const float* const (&pa)[BM / 32], const float* const (&pb)[BN / 32], float* smem,
+                                           int wave_s) {
+  constexpr int STAGE = (BM + BN) * 32;
   // the instruction's immediate offset is added to BOTH the global address and the LDS address (M0 base + offset +
   // lane*16), so the LDS destination is pre-biased by -IMM
-  float* la = smem + STG * STAGE + wave_s * 32 * 32 - IMM / 4;
-  float* lb = la + 128 * 32;
+  float* la = smem + STG * STAGE + wave_s * (BM / 4) * 32 - IMM / 4;
+  float* lb = smem + STG * STAGE + BM * 32 + wave_s * (BN / 4) * 32 - IMM / 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < BM / 32; ++j)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
                                      (__attribute__((address_space(3))) void*)(la + j * 8 * 32), 16, IMM, 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < BN / 32; ++j)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
                                      (__attribute__((address_space(3))) void*)(lb + j * 8 * 32), 16, IMM, 0);
 }
 
-template <int STG>
+template <int BM, int BN, int STG>
 __device__ __forceinline__ void glds_mfma(f32x16 (&acc)[2][2], const float* const (&fa)[4], const float* const (&fb)[4]) {
-  constexpr int STAGE = 256 * 32;
+  constexpr int STAGE = (BM + BN) * 32;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 a[2], b[2];
@@ -361,10 +362,13 @@ __device__ __forceinline__ void glds_mfma(f32x16 (&acc)[2][2], const float* cons
   }
 }
 
-template <int EPI>
+// Block BM x BN with 4 waves laid out WM x WN, every wave a 64 x 64 sub-tile: <128,128,2,2> and <256,64,4,1>.
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemmParams p) {
-  constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 2, TN = 2;
+  constexpr int TM = 2, TN = 2;
+  static_assert(BM / WM == 64 && BN / WN == 64 && WM * WN == 4, "wave tile is 64 x 64");
   constexpr int STAGE = (BM + BN) * 32;
+  constexpr int AJ = BM / 32, BJ = BN / 32;     // DMA instructions per wave per stage (8 rows each)
   __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -378,31 +382,35 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
 
   const int srow = lane >> 3, pslot = lane & 7;
   const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
-  RowDesc ad[4];
-  int acol[4];
+  RowDesc ad[AJ];
+  int acol[AJ];
   unsigned arow_ok = 0;
-  const float* bptr[4];                // weight row pointers (tap 0, chunk 0)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = wave_s * 32 + j * 8 + srow;
+  for (int j = 0; j < AJ; ++j) {
+    const int r = wave_s * (BM / 4) + j * 8 + srow;
     acol[j] = (pslot ^ ((r >> 1) & 7)) * 4;
     const int m = m0 + r;
     ad[j] = decode_row(p, m);
     if (m < p.M) arow_ok |= 1u << j;
+  }
+  const float* bptr[BJ];               // weight row pointers (tap 0, chunk 0)
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int r = wave_s * (BN / 4) + j * 8 + srow;
     const int n = min(n0 + r, p.Nc - 1);
-    bptr[j] = p.B + (long long)n * p.T * p.Ci + acol[j];
+    bptr[j] = p.B + (long long)n * p.T * p.Ci + (pslot ^ ((r >> 1) & 7)) * 4;
   }
 
   const int kpt = p.Ci >> 5;          // K tiles per tap (even)
   const int hpt = kpt >> 1;           // tile pairs per tap
   const int npairs = p.ntaps * hpt;
 
-  const float* pa[4];
-  const float* pb[4];
+  const float* pa[AJ];
+  const float* pb[BJ];
   auto set_tap = [&](int pack) {
     const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AJ; ++j) {
       const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
       const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
       const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
@@ -410,8 +418,9 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
       const unsigned long long msk = in ? ~0ull : 0ull;
       pa[j] = reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(src) & msk) |
                                              (reinterpret_cast<unsigned long long>(g_zero_line + acol[j]) & ~msk));
-      pb[j] = bptr[j] + (long long)wt * p.Ci;
     }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) pb[j] = bptr[j] + (long long)wt * p.Ci;
   };
 
   f32x16 acc[TM][TN];
@@ -436,15 +445,15 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
   int tap_n = 0, cp = 0;
   if (npairs > 0) {
     set_tap(p.tap[0]);
-    glds_issue<0, 0>(pa, pb, smem, wave_s);                      // tile 0
+    glds_issue<BM, BN, 0, 0>(pa, pb, smem, wave_s);               // tile 0
   }
   int pack_next = p.ntaps > 1 ? p.tap[1] : 0;
   for (int pr = 0; pr < npairs; ++pr) {
     // ---- even tile (stage 0) ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    glds_issue<1, 128>(pa, pb, smem, wave_s);                    // odd tile of the pair: same tap, next 32 channels
-    glds_mfma<0>(acc, fa, fb);
+    glds_issue<BM, BN, 1, 128>(pa, pb, smem, wave_s);             // odd tile of the pair: same tap, next 32 channels
+    glds_mfma<BM, BN, 0>(acc, fa, fb);
     // ---- odd tile (stage 1) ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -456,11 +465,13 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
         pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pa[j] += 64; pb[j] += 64; }
+        for (int j = 0; j < AJ; ++j) pa[j] += 64;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pb[j] += 64;
       }
-      glds_issue<0, 0>(pa, pb, smem, wave_s);                    // even tile of the next pair
+      glds_issue<BM, BN, 0, 0>(pa, pb, smem, wave_s);             // even tile of the next pair
     }
-    glds_mfma<1>(acc, fa, fb);
+    glds_mfma<BM, BN, 1>(acc, fa, fb);
   }
   __syncthreads();
 
@@ -644,7 +655,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
-#define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<E>), dim3(grid), dim3(256), 0, s, p)
+#define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_GLDS2)
 #undef LAUNCH_GLDS2
     } else if (gg_use_glds()) {
@@ -659,9 +670,15 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
+#define LAUNCH_NARROW2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<256, 64, 4, 1, E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_NARROW2)
+#undef LAUNCH_NARROW2
+    } else {
 #define LAUNCH_NARROW(E) hipLaunchKernelGGL((gather_gemm_kernel<256, 64, 4, 1, E>), dim3(grid), dim3(256), 0, s, p)
-    GG_EPI_SWITCH(LAUNCH_NARROW)
+      GG_EPI_SWITCH(LAUNCH_NARROW)
 #undef LAUNCH_NARROW
+    }
   }
   prof_end(s);
   return check_launch("gather_gemm");
@@ -838,11 +855,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // debugging aid: resident blocks per CU the runtime predicts for the main kernel variants
 int debug_occupancy(int* out4) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_glds_kernel<EPI_STATS>, 256, 0) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_glds2_kernel<128, 128, 2, 2, EPI_STATS>, 256, 0) != hipSuccess) return 1;
   out4[0] = n;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_kernel<128, 128, 2, 2, EPI_STATS>, 256, 0) != hipSuccess) return 1;
   out4[1] = n;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_kernel<256, 64, 4, 1, EPI_STATS>, 256, 0) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_glds2_kernel<256, 64, 4, 1, EPI_STATS>, 256, 0) != hipSuccess) return 1;
   out4[2] = n;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<128, 128>, 256, 0) != hipSuccess) return 1;
   out4[3] = n;
