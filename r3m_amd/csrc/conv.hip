@@ -852,6 +852,186 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// =====================================================================================================
+// wgrad, direct-to-LDS staging. Same GEMM as wgrad_kernel; the [k][channel] LDS image is lane-linear (a row of 64 or 128
+// floats = 256/512 B, one DMA instruction covers 4 or 2 consecutive k rows), so no swizzle is needed and the b32 fragment
+// reads stay conflict-free. Two stages, one barrier per K step, the K loop unrolled by two so stage offsets are
+// immediates. The dY operand and the X operand of 1x1/stride-1 convs advance by a constant 32 rows per step (one 64-bit
+// add per DMA); only the X operand of 3x3 / strided convs keeps a per-step (oy, ox) walk. Rows past the end of the split
+// and padding taps read the zero buffer.
+// =====================================================================================================
+template <int BMt, int BNt>
+__global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
+  constexpr int BK = 32;
+  constexpr int TM = BMt / 64, TN = BNt / 64;
+  constexpr int A_RPI = 256 / BMt, B_RPI = 256 / BNt;   // k rows covered by one 1 KiB DMA instruction
+  constexpr int AJ = 8 / A_RPI, BJ = 8 / B_RPI;         // instructions per wave per stage (8 k rows per wave)
+  constexpr int STAGE = BK * (BMt + BNt);
+  __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s >> 1, wn = wave_s & 1;
+  const int T = p.KH * p.KW;
+  const int tap = blockIdx.x % T;
+  const int tile = blockIdx.x / T;
+  const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
+  const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int ms = blockIdx.y * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  const int hw = p.Ho * p.Wo;
+
+  // lane -> (k row within the instruction, first channel)
+  const int a_k = lane / (BMt / 4), a_c = (lane % (BMt / 4)) * 4;
+  const int b_k = lane / (BNt / 4), b_c = (lane % (BNt / 4)) * 4;
+  const bool a_cv = (co0 + a_c) < p.Co, b_cv = (ci0 + b_c) < p.Ci;
+  const float* zl = g_zero_line + (lane & 7) * 4;
+
+  // A operand (dY): row of instruction j at K step 0
+  int a_m[AJ];
+  const float* a_ptr[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    a_m[j] = ms + wave_s * 8 + j * A_RPI + a_k;
+    a_ptr[j] = p.dY + (long long)a_m[j] * p.Co + (a_cv ? co0 + a_c : 0);
+  }
+  // B operand (X)
+  const int q32 = 32 / p.Wo, r32 = 32 - q32 * p.Wo;
+  const bool fast_adv = (q32 + 1) <= p.Ho;
+  const long long img = (long long)p.Hi * p.Wi * p.Ci;
+  int b_m[BJ];
+  const float* b_ptr[BJ];   // simple rows: running pointer; otherwise image base pointer of the row's frame
+  int xoy[BJ], xox[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    b_m[j] = ms + wave_s * 8 + j * B_RPI + b_k;
+    xoy[j] = 0; xox[j] = 0;
+    if (p.simple_rows) {
+      b_ptr[j] = p.X + (long long)b_m[j] * p.Ci + (b_cv ? ci0 + b_c : 0);
+    } else {
+      const int n = b_m[j] / hw;
+      const int rem = b_m[j] - n * hw;
+      xoy[j] = rem / p.Wo;
+      xox[j] = rem - xoy[j] * p.Wo;
+      b_ptr[j] = p.X + (long long)n * img + (b_cv ? ci0 + b_c : 0);
+    }
+  }
+  const long long a_step = 32LL * p.Co, b_step = 32LL * p.Ci;
+
+  auto sel = [](const float* s, const float* z, bool ok) {
+    const unsigned long long msk = ok ? ~0ull : 0ull;
+    return reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(s) & msk) |
+                                          (reinterpret_cast<unsigned long long>(z) & ~msk));
+  };
+  // issue the DMA of the K step whose first row is (a_m / b_m), then advance the descriptors by 32 rows
+  auto issue = [&](int stage) {
+    float* la = smem + stage * STAGE + wave_s * 8 * BMt;
+    float* lb = smem + stage * STAGE + BK * BMt + wave_s * 8 * BNt;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const float* src = sel(a_ptr[j], zl, (a_m[j] < me) && a_cv);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(la + j * A_RPI * BMt), 16, 0, 0);
+      a_m[j] += 32;
+      a_ptr[j] += a_step;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const float* src;
+      if (p.simple_rows) {
+        src = sel(b_ptr[j], zl, (b_m[j] < me) && b_cv);
+        b_ptr[j] += b_step;
+      } else {
+        const int iy = xoy[j] * p.stride + kh - p.pad, ix = xox[j] * p.stride + kw - p.pad;
+        const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (b_m[j] < me) && b_cv;
+        const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+        src = sel(b_ptr[j] + ((long long)iyc * p.Wi + ixc) * p.Ci, zl, in);
+        if (fast_adv) {
+          int ox = xox[j] + r32, oy = xoy[j] + q32;
+          const bool cx = ox >= p.Wo;
+          ox = cx ? ox - p.Wo : ox;
+          oy = cx ? oy + 1 : oy;
+          const bool cy = oy >= p.Ho;
+          oy = cy ? oy - p.Ho : oy;
+          b_ptr[j] = cy ? b_ptr[j] + img : b_ptr[j];
+          xox[j] = ox; xoy[j] = oy;
+        } else {
+          const int m = b_m[j] + 32;
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          xoy[j] = rem / p.Wo;
+          xox[j] = rem - xoy[j] * p.Wo;
+          b_ptr[j] = p.X + (long long)n * img + (b_cv ? ci0 + b_c : 0);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lb + j * B_RPI * BNt), 16, 0, 0);
+      b_m[j] += 32;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  const float* fragA = smem + lh * BMt + wm * TM * 32 + lrow;
+  const float* fragB = smem + BK * BMt + lh * BNt + wn * TN * 32 + lrow;
+  auto mfma_stage = [&](const float* fa, const float* fb) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = fa[kk * 2 * BMt + t * 32];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = fb[kk * 2 * BNt + t * 32];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  const int nk = (me - ms + BK - 1) / BK;
+  if (nk > 0) issue(0);
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue(1);
+    mfma_stage(fragA, fragB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 2 < nk) issue(0);
+    mfma_stage(fragA + STAGE, fragB + STAGE);
+  }
+  if (kt < nk) {   // odd tail
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    mfma_stage(fragA, fragB);
+  }
+
+  float* out = p.out + (long long)blockIdx.y * p.Co * T * p.Ci;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (co >= p.Co) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
+        if (ci < p.Ci) out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
+      }
+    }
+}
+
 // debugging aid: resident blocks per CU the runtime predicts for the main kernel variants
 int debug_occupancy(int* out4) {
   int n = 0;
@@ -866,13 +1046,23 @@ int debug_occupancy(int* out4) {
   return 0;
 }
 
+static bool wg_use_glds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_WG_GLDS"); v = (e && *e == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
 
+// Split-K factor: enough blocks for two full waves of resident blocks (128x128: 2 blocks/CU x 256 CUs; 64x64: 5/CU), as few
+// splits as that allows (every split writes and re-reads a full dW slab), never fewer than 8 K steps per block.
 int wgrad_pick_split(int M, int Co, int Ci, int T) {
-  const int bt = wg_wide(Co, Ci) ? 128 : 64;
+  const bool wide = wg_wide(Co, Ci);
+  const int bt = wide ? 128 : 64;
   const long long tiles = (long long)ceil_div(Co, bt) * ceil_div(Ci, bt) * T;
-  long long split = (2048 + tiles - 1) / tiles;
-  const long long max_split = (M + 255) / 256;  // at least 8 K-steps per block
+  const long long target = wide ? 1024 : 2560;
+  long long split = (target + tiles / 2) / tiles;
+  const long long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   long long rps = ((M + split - 1) / split + 31) / 32 * 32;
@@ -891,12 +1081,14 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     p.tilesN = ceil_div(p.Ci, 128);
     const int tiles = ceil_div(p.Co, 128) * p.tilesN * T;
     prof_begin(KC_WGRAD_WIDE, flops, p.M, p.Co, p.Ci, T, s);
-    hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
     prof_begin(KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
-    hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
   }
   prof_end(s);
   return check_launch("wgrad");
