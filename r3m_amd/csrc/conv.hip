@@ -1061,7 +1061,7 @@ int wgrad_pick_split(int M, int Co, int Ci, int T) {
   const int bt = wide ? 128 : 64;
   const long long tiles = (long long)ceil_div(Co, bt) * ceil_div(Ci, bt) * T;
   const long long target = wide ? 1024 : 2560;
-  long long split = (target + tiles / 2) / tiles;
+  long long split = target / tiles;   // floor: never spill a few blocks into an extra wave
   const long long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
