@@ -1,0 +1,93 @@
+"""-m gpu: the data-parallel wrapper end to end with the REAL engine backward: two ranks share the one GPU of the test box
+(gloo backend on CUDA tensors — RCCL refuses two ranks on one device), each runs the encoder on its half of the frames,
+the staged gradient all-reduce runs from the backward stage hooks, and the averaged gradients must equal a single-process
+run on the full batch. BatchNorm runs on running statistics and the loss is the LP term only, so the two computations
+are mathematically identical ('N ranks x B/N clips reproduces 1 rank x B gradients with BN in eval mode')."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(size):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import detgen
+    from r3m_amd import R3M
+    m = R3M("cuda", 1e-4, 1024, size=size, l2weight=1.0, l1weight=0.5, langweight=0.0, tcnweight=0.0)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()})
+    return m.to("cuda:0")
+
+
+def _lp_backward(model, frames):
+    """LP loss on running-stat BatchNorm: full = mean||h||_2 + 0.5 mean||h||_1 over the frames."""
+    core = model.module
+    core.convnet.eval()
+    core.encoder_opt.zero_grad()
+    h = model(frames)
+    loss = torch.linalg.norm(h, ord=2, dim=-1).mean() + 0.5 * torch.linalg.norm(h, ord=1, dim=-1).mean()
+    loss.backward()
+    model.finish_gradient_sync()
+    torch.cuda.synchronize()
+    return core.convnet.flat_grads().clone()
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle import detgen
+        from r3m_amd.parallel import DistributedR3M, make_network_wrapper
+        m = _build(18)
+        net = make_network_wrapper(m)
+        assert isinstance(net, DistributedR3M)
+        frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to("cuda:0")
+        g = _lp_backward(net, frames[rank * 4:(rank + 1) * 4])
+        q.put((rank, g.cpu().numpy()))
+        dist.barrier()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process(hip):
+    from oracle import detgen
+    from r3m_amd.parallel import SingleDevice
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r, v in res.items():
+        assert not isinstance(v, str), f"rank {r}: {v}"
+    np.testing.assert_array_equal(res[0], res[1])          # both ranks hold the same averaged gradient
+    single = SingleDevice(_build(18))
+    frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to("cuda:0")
+    g1 = _lp_backward(single, frames).cpu().numpy()
+    err = np.abs(res[0] - g1).max() / np.abs(g1).max()
+    print("ddp vs single max-rel", err)
+    assert err < 2e-5
