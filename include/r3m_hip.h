@@ -82,13 +82,15 @@ int r3m_bn_train_coeffs(const float* stats, int stats_rows, long long count, con
 int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* coef, int C, r3m_stream_t stream);
 /* z = [relu](scale*y + shift [+ r] [+ scale2*y2 + shift2]) ; pass r for the identity branch, or y2+coef2 for a
- * downsample branch (then r must be NULL). */
+ * downsample branch (then r must be NULL). maskbits (optional): 1 bit per element = [z > 0], rows*C/8 bytes (float4 index i
+ * owns nibble i&7 of 32-bit word i>>3) — what the backward reads instead of z. */
 int r3m_bn_act_fwd(const float* y, const float* coef, const float* r, const float* y2, const float* coef2, float* z,
-                   long long rows, int C, int relu, r3m_stream_t stream);
-/* g = dz * [mask], mask = (zmask > 0) if zmask else (scale*y+shift > 0); dgamma = sum g*yhat, dbeta = sum g,
+                   long long rows, int C, int relu, unsigned* maskbits, r3m_stream_t stream);
+/* g = dz * [mask], mask = zbits (bit mask from r3m_bn_act_fwd) if given, else (zmask > 0) if given, else
+ * (scale*y+shift > 0); dgamma = sum g*yhat, dbeta = sum g,
  * dy = scale*(g - mean(g) - yhat*mean(g*yhat)) (batch stats) or scale*g (use_batch_stats=0). */
-int r3m_bn_bwd(const float* dz, const float* zmask, const float* y, const float* coef, float* dgamma, float* dbeta, float* dy,
-               void* workspace, size_t workspace_bytes, long long rows, int C, int use_batch_stats, int accumulate,
+int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const float* y, const float* coef, float* dgamma,
+               float* dbeta, float* dy, void* workspace, size_t workspace_bytes, long long rows, int C, int use_batch_stats, int accumulate,
                r3m_stream_t stream);
 /* MaxPool2d(3,2,1) and AdaptiveAvgPool2d(1)+flatten, NHWC */
 int r3m_maxpool_fwd(const float* z, float* p, unsigned char* argmax, int N, int Hi, int Wi, int C, r3m_stream_t stream);

@@ -48,8 +48,8 @@ SIGNATURES = {
     "r3m_bn_workspace_bytes": (c_sz, [c_ll, c_i]),
     "r3m_bn_train_coeffs": (c_i, [c_f, c_i, c_ll, c_f, c_f, c_f, c_f, c_fl, c_fl, c_f, c_f, c_sz, c_i, c_f]),
     "r3m_bn_eval_coeffs": (c_i, [c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_f]),
-    "r3m_bn_act_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f]),
-    "r3m_bn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_f]),
+    "r3m_bn_act_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f, c_f]),
+    "r3m_bn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_f]),
     "r3m_maxpool_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_maxpool_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_avgpool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),

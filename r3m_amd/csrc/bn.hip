@@ -126,9 +126,10 @@ template <int MODE>  // 0: plain, 1: + R, 2: + affine(Y2)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ R,
                                                           const float* __restrict__ scale2, const float* __restrict__ shift2,
-                                                          float* __restrict__ Z, long long n4, int c4mask, int relu) {
+                                                          float* __restrict__ Z, long long n4, int c4mask, int relu,
+                                                          unsigned* __restrict__ maskbits) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
+  if (i >= n4) return;   // n4 is a multiple of 8 when maskbits is used: an 8-lane nibble group is all in or all out
   const int c = ((int)(i & c4mask)) * 4;
   const f32x4 y = ld4(Y + i * 4);
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
@@ -150,22 +151,31 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (int e = 0; e < 4; ++e) z[e] = fmaxf(z[e], 0.f);
   }
   st4(Z + i * 4, z);
+  if (maskbits) {
+    // ReLU mask of the stored activation, 1 bit per element: float4 index i owns nibble (i & 7) of word i >> 3. The
+    // backward kernels read this (1/32 of the bytes) instead of re-reading the activation just to test z > 0.
+    unsigned v = ((z[0] > 0.f) ? 1u : 0u) | ((z[1] > 0.f) ? 2u : 0u) | ((z[2] > 0.f) ? 4u : 0u) | ((z[3] > 0.f) ? 8u : 0u);
+    v <<= 4 * (threadIdx.x & 7);
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+    if ((threadIdx.x & 7) == 0) maskbits[i >> 3] = v;
+  }
 }
 
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
-                      const float* shift2, float* Z, long long rows, int C, int relu, hipStream_t s) {
+                      const float* shift2, float* Z, long long rows, int C, int relu, unsigned* maskbits, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_act_fwd: C=%d must be a power of two >= 4", C);
+  R3M_REQUIRE(!maskbits || (rows * C / 4) % 8 == 0, "bn_act_fwd: bit mask needs rows*C to be a multiple of 32");
   const long long n4 = rows * C / 4;
   const int grid = ceil_div(n4, 256);
   const int c4mask = C / 4 - 1;
   if (R && scale2)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
   else if (R)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
   else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
   return check_launch("bn_act_fwd");
 }
 
@@ -175,8 +185,13 @@ int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, co
 // identity branch) or recomputed from y with the very same fmaf the forward used (no extra read).
 // Work split: a block owns RB consecutive rows x up to 1024 channels; each thread keeps 4 channels in registers.
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mask_nibble(const unsigned* bits, long long elem_off) {
+  const long long i4 = elem_off >> 2;
+  return (bits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
-                                                             const float* __restrict__ Y, const float* __restrict__ scale,
+                                                             const unsigned* __restrict__ Zbits, const float* __restrict__ Y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, float* __restrict__ partials,
                                                              long long rows, int C, int cpb4, int rows_per_block) {
@@ -194,7 +209,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const f32x4 y = ld4(Y + off);
     const f32x4 dz = ld4(dZ + off);
     f32x4 g;
-    if (Zmask) {
+    if (Zbits) {
+      const unsigned nb = mask_nibble(Zbits, off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = ((nb >> e) & 1u) ? dz[e] : 0.f;
+    } else if (Zmask) {
       const f32x4 z = ld4(Zmask + off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
@@ -235,13 +254,14 @@ int bn_bwd_partial_rows(long long rows, int C) {
   return nblk;
 }
 
-int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
-                         const float* mean, const float* invstd, float* partials, long long rows, int C, hipStream_t s) {
+int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
+                         hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce: C=%d must be a power of two >= 4", C);
   int cpb4, rpb, nblk;
   bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s, dZ, Zmask, Y, scale, shift,
-                     mean, invstd, partials, rows, C, cpb4, rpb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s, dZ, Zmask, Zbits, Y, scale,
+                     shift, mean, invstd, partials, rows, C, cpb4, rpb);
   return check_launch("bn_bwd_reduce");
 }
 
@@ -272,7 +292,7 @@ int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long coun
 
 // pass 2:  dY = scale * (g - c1 - yhat * c2)       (c1 = mean(g), c2 = mean(g*yhat); both 0 in eval mode)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
-                                                            const float* __restrict__ Y, const float* __restrict__ scale,
+                                                            const unsigned* __restrict__ Zbits, const float* __restrict__ Y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ c1,
                                                             const float* __restrict__ c2, float* __restrict__ dY,
@@ -285,7 +305,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
   f32x4 g;
-  if (Zmask) {
+  if (Zbits) {
+    const unsigned nb = (Zbits[i >> 3] >> (4 * (int)(i & 7))) & 15u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = ((nb >> e) & 1u) ? dz[e] : 0.f;
+  } else if (Zmask) {
     const f32x4 z = ld4(Zmask + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
@@ -302,13 +326,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   st4(dY + i * 4, o);
 }
 
-int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
-                        const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
+int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
                         long long rows, int C, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_apply: C=%d must be a power of two >= 4", C);
   const long long n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, dZ, Zmask, Y, scale, shift, mean,
-                     invstd, c1, c2, dY, n4, C / 4 - 1);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, dZ, Zmask, Zbits, Y, scale, shift,
+                     mean, invstd, c1, c2, dY, n4, C / 4 - 1);
   return check_launch("bn_bwd_apply");
 }
 

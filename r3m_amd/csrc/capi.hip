@@ -77,8 +77,8 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
                   int accumulate, int* gd_io, hipStream_t s);
 int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
                         int Co, int k, int stride, int pad, int flags, hipStream_t s);
-int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, int N, int Hi, int Wi,
-                      int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
+int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
 int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
                       int stride, int pad, int accumulate, hipStream_t s);
 size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
@@ -192,7 +192,7 @@ int r3m_conv2d_dgrad(const float* dy, const float* w, float* dx, void* ws, size_
   R3M_REQUIRE(ws_bytes >= r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k), "conv2d_dgrad: workspace too small");
   float* Wt = static_cast<float*>(ws);
   if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
-  return conv_dgrad_launch(dy, Wt, dx, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, S(stream));
+  return conv_dgrad_launch(dy, Wt, dx, nullptr, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, S(stream));
 }
 size_t r3m_conv2d_wgrad_workspace_bytes(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
   return conv_wgrad_ws_floats(N, Hi, Wi, Ci, Co, k, stride, pad) * 4;
@@ -225,23 +225,23 @@ int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, c
   return launch_bn_eval_coeffs(gamma, beta, rm, rv, eps, coef, coef + C, coef + 2 * C, coef + 3 * C, C, S(stream));
 }
 int r3m_bn_act_fwd(const float* y, const float* coef, const float* r, const float* y2, const float* coef2, float* z, long long rows,
-                   int C, int relu, r3m_stream_t stream) {
+                   int C, int relu, unsigned* maskbits, r3m_stream_t stream) {
   R3M_REQUIRE(!(r && y2), "bn_act_fwd: pass either r (identity) or y2/coef2 (downsample), not both");
-  if (y2) return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, y2, coef2 + 2 * C, coef2 + 3 * C, z, rows, C, relu, S(stream));
-  return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, r, nullptr, nullptr, z, rows, C, relu, S(stream));
+  if (y2) return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, y2, coef2 + 2 * C, coef2 + 3 * C, z, rows, C, relu, maskbits, S(stream));
+  return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, r, nullptr, nullptr, z, rows, C, relu, maskbits, S(stream));
 }
-int r3m_bn_bwd(const float* dz, const float* zmask, const float* y, const float* coef, float* dgamma, float* dbeta, float* dy,
-               void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
+int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const float* y, const float* coef, float* dgamma,
+               float* dbeta, float* dy, void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
   R3M_REQUIRE(ws_bytes >= r3m_bn_workspace_bytes(rows, C), "bn_bwd: workspace too small (need %zu)", r3m_bn_workspace_bytes(rows, C));
   float* partial = static_cast<float*>(ws);
   double* acc = reinterpret_cast<double*>(static_cast<char*>(ws) + bn_acc_off(rows, C));
   float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
-  if (int e = launch_bn_bwd_reduce(dz, zmask, y, scale, shift, mean, invstd, partial, rows, C, S(stream))) return e;
+  if (int e = launch_bn_bwd_reduce(dz, zmask, zbits, y, scale, shift, mean, invstd, partial, rows, C, S(stream))) return e;
   const int prow = bn_bwd_partial_rows(rows, C);
   if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
   if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
-  return launch_bn_bwd_apply(dz, zmask, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, S(stream));
+  return launch_bn_bwd_apply(dz, zmask, zbits, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, S(stream));
 }
 int r3m_maxpool_fwd(const float* z, float* p, unsigned char* am, int N, int Hi, int Wi, int C, r3m_stream_t stream) {
   return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, S(stream));

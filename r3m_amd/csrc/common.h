@@ -42,7 +42,8 @@ struct GatherGemmParams {
   const float* B;      // weights [Nc][T][Ci]  (row = output column, K contiguous)
   float* out;          // output activations, NHWC [N, Ho, Wo, Nc]
   const float* add0;   // EPI_MASKED_ADD: gradient tensor, same shape as out
-  const float* add1;   // EPI_MASKED_ADD: mask source (post-ReLU activation), same shape as out
+  const float* add1;   // EPI_MASKED_ADD / EPI_MASK_OUT: mask source (post-ReLU activation), same shape as out
+  const unsigned* addbits;  // EPI_MASKED_ADD: optional 1-bit/element ReLU mask of that activation (used instead of add1)
   const float* bias;   // EPI_BIAS: [Nc]
   float* stats;        // EPI_STATS: [gridM][2][Nc]
   int N, Hi, Wi, Ci;
@@ -94,14 +95,15 @@ int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, c
 int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                           float eps, float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s);
 int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
-                      const float* shift2, float* Z, long long rows, int C, int relu, hipStream_t s);
+                      const float* shift2, float* Z, long long rows, int C, int relu, unsigned* maskbits, hipStream_t s);
 int bn_bwd_partial_rows(long long rows, int C);
-int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
-                         const float* mean, const float* invstd, float* partials, long long rows, int C, hipStream_t s);
+int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
+                         hipStream_t s);
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
                                 float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s);
-int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const float* Y, const float* scale, const float* shift,
-                        const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
+int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
                         long long rows, int C, hipStream_t s);
 int launch_maxpool_fwd(const float* Z, float* P, unsigned char* amax, int N, int Hi, int Wi, int C, hipStream_t s);
 int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, int N, int Hi, int Wi, int C, hipStream_t s);

@@ -134,9 +134,17 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
         if (EPI & EPI_BIAS) v += bias4;
         if (EPI & EPI_ACCUM) v += ldg4(dst);
         if (EPI & EPI_MASKED_ADD) {
-          const f32x4 g = ldg4(p.add0 + roff + gcol), z = ldg4(p.add1 + roff + gcol);
+          const f32x4 g = ldg4(p.add0 + roff + gcol);
+          if (p.addbits) {
+            const long long i4 = (roff + gcol) >> 2;
+            const unsigned nb = (p.addbits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (z[e] > 0.f) ? g[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? g[e] : 0.f;
+          } else {
+            const f32x4 z = ldg4(p.add1 + roff + gcol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (z[e] > 0.f) ? g[e] : 0.f;
+          }
         }
         if (EPI & EPI_RELU) {
 #pragma unroll

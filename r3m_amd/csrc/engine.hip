@@ -37,6 +37,7 @@ struct BlockSpec {
   int ds;                 // downsample conv index or -1
   long long in_off;       // arena offset of the block input
   long long out_off;      // arena offset of the block output
+  long long mask_off;     // arena offset of the block output's 1-bit ReLU mask (rows*C/32 words)
   int Ho, Wo, Co;
   int stage;              // 0..3 = layer1..layer4
 };
@@ -182,6 +183,7 @@ Plan* plan_create(int size, int F) {
     B.in_off = cur_in;
     for (int j = 0; j < B.nconv - 1; ++j) P.convs[B.conv[j]].Z_off = take(act_elems(P.convs[B.conv[j]]));
     B.out_off = take(Fll * B.Ho * B.Wo * B.Co);
+    B.mask_off = take((Fll * B.Ho * B.Wo * B.Co + 31) / 32);
     cur_in = B.out_off;
   }
   P.partial_off = take(partial_max);
@@ -233,13 +235,13 @@ int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, 
 }
 
 // dX[N,Hi,Wi,Ci] = dgrad of conv(k, stride, pad) given dY[N,Ho,Wo,Co] and Wt[Ci][k*k][Co]
-int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, int N, int Hi, int Wi,
-                      int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s) {
+int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s) {
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   R3M_REQUIRE(stride == 1 || stride == 2, "dgrad: stride %d", stride);
   GatherGemmParams g;
   memset(&g, 0, sizeof g);
-  g.A = dY; g.B = Wt; g.out = dX; g.add0 = add0; g.add1 = add1;
+  g.A = dY; g.B = Wt; g.out = dX; g.add0 = add0; g.add1 = add1; g.addbits = addbits;
   g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co;   // the GEMM "input" is dY
   g.Ho = Hi; g.Wo = Wi; g.Nc = Ci;
   g.is = 1; g.T = k * k; g.flags = flags;
@@ -350,7 +352,7 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   TRY(conv_bn_coeffs(c, L0, col, w160, 160, 1, 1, 0, 112, 112, F));
   float* Z0 = arena + L0.Z_off;
   const long long rows0 = (long long)F * 112 * 112;
-  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, s));
+  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, nullptr, s));
   TRY(launch_maxpool_fwd(Z0, arena + P.P0_off, reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, s));
   // ---- residual stages ----
   for (const BlockSpec& B : P.blocks) {
@@ -362,20 +364,21 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
       if (j < B.nconv - 1) {
         const long long rows = (long long)F * L.Ho * L.Wo;
         TRY(launch_bn_act_fwd(arena + L.Y_off, coef(c, L, 2), coef(c, L, 3), nullptr, nullptr, nullptr, arena + L.Z_off, rows,
-                              L.Co, 1, s));
+                              L.Co, 1, nullptr, s));
         cur = arena + L.Z_off;
       }
     }
     const ConvSpec& LL = P.convs[B.conv[B.nconv - 1]];
     const long long rows = (long long)F * B.Ho * B.Wo;
+    unsigned* mask = reinterpret_cast<unsigned*>(arena + B.mask_off);   // [z > 0] bits of the block output, for backward
     if (B.ds >= 0) {
       const ConvSpec& Ld = P.convs[B.ds];
       TRY(conv_bn(c, Ld, Xin));
       TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), arena + Ld.Y_off, coef(c, Ld, 2), coef(c, Ld, 3),
-                            arena + B.out_off, rows, B.Co, 1, s));
+                            arena + B.out_off, rows, B.Co, 1, mask, s));
     } else {
       TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), Xin, nullptr, nullptr, arena + B.out_off, rows,
-                            B.Co, 1, s));
+                            B.Co, 1, mask, s));
     }
   }
   const BlockSpec& last = P.blocks.back();
@@ -384,18 +387,18 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
 }
 
 // BatchNorm(+ReLU / residual mask) backward of layer L: dZ -> dY, parameter gradients into the flat gradient buffer
-static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const float* Zmask, float* dY) {
+static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY) {
   Plan& P = c.P;
   const long long rows = (long long)P.F * L.Ho * L.Wo;
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   const float* Y = c.arena + L.Y_off;
-  TRY(launch_bn_bwd_reduce(dZ, Zmask, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.s));
+  TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.s));
   const int prow = bn_bwd_partial_rows(rows, L.Co);
   TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
   TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
                                   coef(c, L, 5), c.accumulate, L.Co, c.s));
-  TRY(launch_bn_bwd_apply(dZ, Zmask, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
+  TRY(launch_bn_bwd_apply(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
                           dY, rows, L.Co, c.s));
   return 0;
 }
@@ -405,10 +408,10 @@ static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
                            c.accumulate, c.s);
 }
 
-static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const float* add1) {
+static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const unsigned* addbits) {
   float* Wt = c.arena + c.P.wt_off;
   TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
-  return conv_dgrad_launch(dY, Wt, dX, add0, add1, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.s);
+  return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.s);
 }
 
 // Backward stages: 0 = avgpool + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem. The gradient w.r.t. the current
@@ -495,13 +498,13 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       const BlockSpec& B = P.blocks[bi];
       if (B.stage != layer) continue;
       const float* dOut = Gp(0);
-      const float* Out = arena + B.out_off;
+      const unsigned* Out = reinterpret_cast<const unsigned*>(arena + B.mask_off);   // [out > 0] bits
       const float* Xin = arena + B.in_off;
       float* Gb = Gp(3);
       float* Gc = Gp(4);
       // last conv of the block: its BatchNorm output joined the residual add, mask comes from the block output
       const float* dz = dOut;
-      const float* zmask = Out;
+      const unsigned* zmask = Out;
       int ai;
       for (int j = B.nconv - 1; j >= 1; --j) {
         const ConvSpec& L = P.convs[B.conv[j]];

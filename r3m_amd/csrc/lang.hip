@@ -201,8 +201,8 @@ int langrew_forward(const float* alle, const float* feats, const int* perm, cons
 }
 
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
-int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, int N, int Hi, int Wi,
-                      int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
+int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
 
 // dscore [15B] -> parameter gradients (flat, same layout as params) and dalle += d/d alle. Needs the workspace left by
 // langrew_forward (X and the four hidden activations).
@@ -233,7 +233,7 @@ int langrew_backward(const float* dscore, const int* iperm, const float* params,
                        accumulate);
     if (int e = check_launch("lang_bias_grad")) return e;
     if (int e = launch_transpose_w(params + d.w[l], Wt, H, 1, K, s)) return e;
-    if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, s))
+    if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, nullptr, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, s))
       return e;
     float* t = dz; dz = nxt; nxt = t;
   }

@@ -177,16 +177,19 @@ def test_bn_train_fwd_bwd(hip, rows, C, mode):
     np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rvd.cpu().numpy(), rv_ref.numpy(), rtol=1e-5, atol=1e-6)
     yd, zd = y.to(DEV), torch.empty((rows, C), device=DEV)
+    # 1-bit ReLU mask of the output (what the engine's backward reads instead of z) when rows*C is a multiple of 32
+    bits = torch.zeros((rows * C + 31) // 32, dtype=torch.int32, device=DEV) if (rows * C) % 32 == 0 else None
+    bits_ptr = None if bits is None else bits.data_ptr()
     coef2 = None
     if mode == "plain":
-        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, st())
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, None, st())
     elif mode == "identity":
         rd = r.to(DEV)
-        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), rd.data_ptr(), None, None, zd.data_ptr(), rows, C, 1, st())
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), rd.data_ptr(), None, None, zd.data_ptr(), rows, C, 1, bits_ptr, st())
     else:
         coef2, _, _ = coeffs(y2, g2, b2, None, None)
         y2d = y2.to(DEV)
-        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, y2d.data_ptr(), coef2.data_ptr(), zd.data_ptr(), rows, C, 1, st())
+        rc = hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, y2d.data_ptr(), coef2.data_ptr(), zd.data_ptr(), rows, C, 1, bits_ptr, st())
     assert rc == 0, hip.r3m_last_error()
     e_max, _ = rel_err(zd.cpu().numpy(), z_ref.detach().numpy())
     assert e_max < 1e-5, f"bn fwd {e_max}"
@@ -197,14 +200,20 @@ def test_bn_train_fwd_bwd(hip, rows, C, mode):
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     dg, db, dyd = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty((rows, C), device=DEV)
     zmask = None if mode == "plain" else zd
-    rc = hip.r3m_bn_bwd(dzd.data_ptr(), None if zmask is None else zmask.data_ptr(), yd.data_ptr(), coef.data_ptr(), dg.data_ptr(),
-                        db.data_ptr(), dyd.data_ptr(), ws.data_ptr(), wsb, rows, C, 1, 0, st())
+    use_bits = bits is not None and mode != "plain"
+    if use_bits:   # the mask bits agree with z > 0 bit for bit
+        zb = (zd.reshape(-1, 8, 4) > 0).to(torch.int64)
+        w = (zb * (1 << (torch.arange(8, device=DEV).view(1, 8, 1) * 4 + torch.arange(4, device=DEV).view(1, 1, 4)))).sum((1, 2))
+        assert torch.equal(w.to(torch.int32), bits)
+    rc = hip.r3m_bn_bwd(dzd.data_ptr(), None if (zmask is None or use_bits) else zmask.data_ptr(), bits_ptr if use_bits else None,
+                        yd.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), dyd.data_ptr(), ws.data_ptr(), wsb, rows, C, 1, 0,
+                        st())
     assert rc == 0, hip.r3m_last_error()
     assert rel_err(dyd.cpu().numpy(), yr.grad.numpy())[0] < 2e-4
     assert rel_err(dg.cpu().numpy(), gr.grad.numpy())[0] < 1e-4
     assert rel_err(db.cpu().numpy(), br.grad.numpy())[0] < 1e-4
     if mode == "downsample":
-        rc = hip.r3m_bn_bwd(dzd.data_ptr(), zd.data_ptr(), y2d.data_ptr(), coef2.data_ptr(), dg.data_ptr(), db.data_ptr(),
+        rc = hip.r3m_bn_bwd(dzd.data_ptr(), zd.data_ptr(), None, y2d.data_ptr(), coef2.data_ptr(), dg.data_ptr(), db.data_ptr(),
                             dyd.data_ptr(), ws.data_ptr(), wsb, rows, C, 1, 0, st())
         assert rc == 0
         assert rel_err(dyd.cpu().numpy(), y2r.grad.numpy())[0] < 2e-4
@@ -220,7 +229,7 @@ def test_bn_eval(hip):
     gd, bd, rmd, rvd, yd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), y.to(DEV)
     assert hip.r3m_bn_eval_coeffs(gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, coef.data_ptr(), C, st()) == 0
     zd = torch.empty((rows, C), device=DEV)
-    assert hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, st()) == 0
+    assert hip.r3m_bn_act_fwd(yd.data_ptr(), coef.data_ptr(), None, None, None, zd.data_ptr(), rows, C, 1, None, st()) == 0
     assert rel_err(zd.cpu().numpy(), z_ref.numpy())[0] < 1e-5
 
 
