@@ -419,14 +419,19 @@ static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flag
 // carried across calls so stages can be issued one by one (the data-parallel wrapper launches the RCCL all-reduce of a
 // finished stage's gradient slice in between).
 //
-// Streams: dgrad(L) and wgrad(L) both consume only dY_L, so wgrad runs on a side stream (event-ordered) while the main
-// stream continues with dgrad(L) -> bn_backward(L-1) -> ... . Two MFMA-bound kernels sharing the chip fill each other's
-// last-wave tails (a 128x128 conv tile runs ~0.3 ms, grids are 2.5-10 waves of tiles) and hide the small kernels between them.
-// dY alternates between A0 and A1 so wgrad(L) has until bn_backward(L-2) to finish; each stage ends with a join.
+// Streams: wgrad(L) only needs dY_L and the saved activations, and nothing on the critical path needs its result before
+// the optimizer. It runs on a side stream, ordered by events so that it overlaps ONLY with the HBM-bound BatchNorm-backward
+// passes of the next layer down (reduce / apply: ~6 TB/s, no MFMA) and never with the MFMA-bound dgrad:
+//     main:  bn_bwd(L) -> [wait wgrad(L+1)] -> dgrad(L) -> bn_bwd(L-1) -> [wait wgrad(L)] -> dgrad(L-1) -> ...
+//     side:                                    wgrad(L)  (starts when dgrad(L) has finished)
+// A bandwidth-bound and a matrix-bound kernel share the CUs without stealing each other's bottleneck resource, and the
+// per-launch timings of the dominant kernel class (gather-GEMM on the main stream) stay unperturbed. Each stage ends with
+// a join. Off by default (R3M_SIDE_STREAM=1 enables it): measured neutral, see side_init().
 static int side_init(Plan& P) {
   if (P.use_side < 0) {
-    // opt-in (R3M_SIDE_STREAM=1): measured +1.7 % step throughput on ResNet-50 F=1280, but co-running kernels inflate each
-    // other's per-launch durations, which blurs the per-kernel roofline accounting of bench.py; off by default.
+    // Opt-in. Measured on ResNet-50 F=1280 (profiles/r01 notes in DESIGN.md): co-running wgrad with the BatchNorm-backward
+    // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
+    // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
     const char* e = getenv("R3M_SIDE_STREAM");
     P.use_side = (e && *e && *e != '0') ? 1 : 0;
   }
@@ -450,7 +455,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   int* role = P.roles;
   auto Gp = [&](int r) { return arena + P.G_off[role[r]]; };
 
-  // dY for conv L has just been produced on the main stream in A[ai]: launch its wgrad on the side stream
+  // call right AFTER dgrad(L) was enqueued on the main stream: wgrad(L) starts on the side stream once that dgrad is done
   auto wgrad_async = [&](const ConvSpec& L, const float* X, const float* dY, int ai) -> int {
     if (!side_on) return wgrad(c, L, X, dY);
     if (hipEventRecord(P.ev_dy, s) != hipSuccess || hipStreamWaitEvent(P.side, P.ev_dy, 0) != hipSuccess) {
@@ -469,6 +474,11 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       P.wg_pending[ai] = false;
     }
     return 0;
+  };
+  // before an MFMA-bound kernel goes to the main stream: every wgrad in flight must have finished
+  auto wait_wgrads = [&]() -> int {
+    TRY(acquire_A(0));
+    return acquire_A(1);
   };
   auto join_side = [&]() -> int {
     if (!side_on) return 0;
@@ -511,27 +521,31 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         const ConvSpec& Lprev = P.convs[B.conv[j - 1]];
         float* dY = next_A(&ai);
         TRY(acquire_A(ai));
-        TRY(bn_backward(c, L, dz, zmask, dY));
-        TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
+        TRY(bn_backward(c, L, dz, zmask, dY));          // HBM-bound: overlaps the previous layer's wgrad
+        TRY(wait_wgrads());
         TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr));
+        TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
         dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward before a later dgrad rewrites it
       }
       const ConvSpec& L1 = P.convs[B.conv[0]];
       float* dY1 = next_A(&ai);
       TRY(acquire_A(ai));
       TRY(bn_backward(c, L1, dz, zmask, dY1));
-      TRY(wgrad_async(L1, Xin, dY1, ai));
+      TRY(wait_wgrads());
       if (B.ds >= 0) {
         const ConvSpec& Ld = P.convs[B.ds];
         TRY(dgrad(c, L1, dY1, Gc, 0, nullptr, nullptr));
+        TRY(wgrad_async(L1, Xin, dY1, ai));
         int ad;
         float* dYd = next_A(&ad);
         TRY(acquire_A(ad));
-        TRY(bn_backward(c, Ld, dOut, Out, dYd));
-        TRY(wgrad_async(Ld, Xin, dYd, ad));
+        TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1)
+        TRY(wait_wgrads());
         TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
+        TRY(wgrad_async(Ld, Xin, dYd, ad));
       } else {
         TRY(dgrad(c, L1, dY1, Gc, EPI_MASKED_ADD, dOut, Out));
+        TRY(wgrad_async(L1, Xin, dY1, ai));
       }
       // C becomes the gradient of the previous block's output; the old D is free (only the main stream ever read it)
       const int t = role[0]; role[0] = role[4]; role[4] = t;
