@@ -72,6 +72,15 @@ int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, void* work
                      int Wi, int Ci, int Co, int k, int stride, int pad, int accumulate, r3m_stream_t stream);
 /* stem input transform: x/255 -> Normalize(mean,std) -> 7x7/2 p3 patches as rows of 160 floats (models_r3m.py:61,97-98) */
 int r3m_stem_im2col(const float* x_nchw, float* col, int frames, r3m_stream_t stream);
+/* the stem as the engine runs it (models_r3m.py:97-99 + torchvision conv1), no patch matrix in HBM:
+ *   r3m_stem_prep      x [frames,3,224,224] fp32 NCHW in 0..255 -> xn [frames,224,224,3] = (x/255 - mean)/std (NHWC)
+ *   r3m_stem_conv_fwd  xn, w_ohwi [64,7,7,3] -> y [frames,112,112,64] (NHWC) (+ BatchNorm partials [frames*49][2][64])
+ *   r3m_stem_conv_wgrad  xn, dy (same layout as y) -> dw_ohwi [64,7,7,3] */
+int r3m_stem_prep(const float* x_nchw, float* xn, int frames, r3m_stream_t stream);
+int r3m_stem_conv_fwd(const float* xn, const float* w_ohwi, float* y, float* stats, int frames, r3m_stream_t stream);
+size_t r3m_stem_conv_wgrad_workspace_bytes(void);
+int r3m_stem_conv_wgrad(const float* xn, const float* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int frames,
+                        int accumulate, r3m_stream_t stream);
 
 /* BatchNorm2d(eps, momentum) train/eval + ReLU + residual add (torchvision BasicBlock/Bottleneck).
  * coef: [4][C] = mean, invstd, scale = gamma*invstd, shift = beta - mean*scale. */

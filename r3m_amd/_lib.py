@@ -45,6 +45,10 @@ SIGNATURES = {
     "r3m_conv2d_wgrad_workspace_bytes": (c_sz, [c_i] * 8),
     "r3m_conv2d_wgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 9 + [c_f]),
     "r3m_stem_im2col": (c_i, [c_f, c_f, c_i, c_f]),
+    "r3m_stem_prep": (c_i, [c_f, c_f, c_i, c_f]),
+    "r3m_stem_conv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f]),
+    "r3m_stem_conv_wgrad_workspace_bytes": (c_sz, []),
+    "r3m_stem_conv_wgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_f]),
     "r3m_bn_workspace_bytes": (c_sz, [c_ll, c_i]),
     "r3m_bn_train_coeffs": (c_i, [c_f, c_i, c_ll, c_f, c_f, c_f, c_f, c_fl, c_fl, c_f, c_f, c_sz, c_i, c_f]),
     "r3m_bn_eval_coeffs": (c_i, [c_f, c_f, c_f, c_f, c_fl, c_f, c_i, c_f]),

@@ -203,6 +203,21 @@ int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw, void* ws, size_
   return conv_wgrad_launch(x, dy, dw, static_cast<float*>(ws), N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, S(stream));
 }
 int r3m_stem_im2col(const float* x, float* col, int frames, r3m_stream_t stream) { return launch_stem_im2col(x, col, frames, S(stream)); }
+int r3m_stem_prep(const float* x, float* xn, int frames, r3m_stream_t stream) {
+  R3M_REQUIRE(x && xn, "stem_prep: null argument");
+  return launch_stem_prep(x, xn, frames, S(stream));
+}
+int r3m_stem_conv_fwd(const float* xn, const float* w_ohwi, float* y, float* stats, int frames, r3m_stream_t stream) {
+  R3M_REQUIRE(xn && w_ohwi && y, "stem_conv_fwd: null argument");
+  return launch_stem_fwd(xn, w_ohwi, y, stats, frames, S(stream));
+}
+size_t r3m_stem_conv_wgrad_workspace_bytes(void) { return (stem_wgrad_ws_floats() + 64 * 160) * 4; }
+int r3m_stem_conv_wgrad(const float* xn, const float* dy, float* dw_ohwi, void* ws, size_t ws_bytes, int frames, int accumulate,
+                        r3m_stream_t stream) {
+  R3M_REQUIRE(xn && dy && dw_ohwi && ws, "stem_conv_wgrad: null argument");
+  R3M_REQUIRE(ws_bytes >= r3m_stem_conv_wgrad_workspace_bytes(), "stem_conv_wgrad: workspace too small");
+  return launch_stem_wgrad(xn, dy, dw_ohwi, static_cast<float*>(ws), frames, accumulate, S(stream));
+}
 
 // workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
 static size_t bn_acc_off(long long rows, int C) {

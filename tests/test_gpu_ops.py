@@ -125,6 +125,38 @@ def test_stem_im2col_conv(hip):
     assert e_max < 2e-5
 
 
+@pytest.mark.parametrize("Fr", [1, 3])
+def test_stem_direct_fwd_wgrad(hip, Fr):
+    """The engine's stem: /255 -> Normalize -> conv 7x7/2 p3 straight from NCHW frames, forward (+BN partials) and wgrad."""
+    x = torch.floor(rnd((Fr, 3, 224, 224), 5, 0.0, 256.0)).clamp(0, 255)
+    w = rnd((64, 3, 7, 7), 6, -0.1, 0.1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d((x / 255.0 - mean) / std, wr, stride=2, padding=3)
+    dy = rnd(tuple(y_ref.shape), 7)
+    y_ref.backward(dy)
+    x_raw, wd = x.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xd = torch.empty((Fr, 224, 224, 3), device=DEV)
+    assert hip.r3m_stem_prep(x_raw.data_ptr(), xd.data_ptr(), Fr, st()) == 0
+    torch.testing.assert_close(xd.cpu(), ((x / 255.0 - mean) / std).permute(0, 2, 3, 1), rtol=0, atol=0)   # same IEEE arithmetic
+    yd = torch.empty((Fr, 112, 112, 64), device=DEV)
+    stats = torch.zeros((Fr * 49, 2, 64), device=DEV)
+    assert hip.r3m_stem_conv_fwd(xd.data_ptr(), wd.data_ptr(), yd.data_ptr(), stats.data_ptr(), Fr, st()) == 0, hip.r3m_last_error()
+    assert rel_err(nchw(yd.cpu()).numpy(), y_ref.detach().numpy())[0] < 2e-5
+    yr = y_ref.detach().double()
+    np.testing.assert_allclose(stats[:, 0].double().sum(0).cpu().numpy(), yr.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3 * float(yr.abs().max()))
+    np.testing.assert_allclose(stats[:, 1].double().sum(0).cpu().numpy(), (yr * yr).sum((0, 2, 3)).numpy(), rtol=1e-4)
+    dyd = nhwc(dy).to(DEV)
+    dwd = torch.empty((64, 7, 7, 3), device=DEV)
+    wsb = hip.r3m_stem_conv_wgrad_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    for acc in (0, 1):
+        assert hip.r3m_stem_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), ws.data_ptr(), wsb, Fr, acc, st()) == 0
+        e_max, _ = rel_err(dwd.cpu().permute(0, 3, 1, 2).numpy(), (acc + 1) * wr.grad.numpy())
+        assert e_max < 5e-5, (acc, e_max)
+
+
 @pytest.mark.parametrize("rows,C", [(2 * 56 * 56, 64), (3 * 14 * 14, 1024), (5 * 49, 2048), (777, 256), (33, 128)])
 @pytest.mark.parametrize("mode", ["plain", "identity", "downsample"])
 def test_bn_train_fwd_bwd(hip, rows, C, mode):
