@@ -1094,59 +1094,62 @@ __device__ __forceinline__ void stem_load_patch(const float* __restrict__ xn, fl
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const GatherGemmParams p) {
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w,
+                                                        const GatherGemmParams p, int ntiles) {
   constexpr int SMEM = 13 * ST_PS + 64 * ST_KS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
-  float* patch = smem;
+  float* patch = smem;                 // also the epilogue's scratch (8704 floats < 13*ST_PS): the weights behind it survive
   float* wl = smem + 13 * ST_PS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x;
-  const long long f = blk / 49;
-  const int lm0 = (blk - (int)f * 49) * 256;    // first output pixel of this block inside its frame (12544 = 49 * 256)
-  const int oy0 = lm0 / 112;
-  stem_load_patch(x, patch, f, 2 * oy0 - 3, 13);
-  {
+  {   // weights once per (persistent) block
     const int n = tid >> 2, q = tid & 3;            // 4 threads per output channel
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh)
       for (int j = q; j < 22; j += 4) wl[n * ST_KS + kh * 22 + j] = (j < 21) ? w[n * 147 + kh * 21 + j] : 0.f;
   }
-  __syncthreads();
-
   const int lrow = lane & 31, lh = lane >> 5;
-  int a_base[2], b_base[2];
+  int b_base[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int lm = lm0 + wave * 64 + t * 32 + lrow;
-    const int oy = lm / 112, ox = lm - oy * 112;
-    a_base[t] = 2 * (oy - oy0) * ST_PS + 6 * ox + lh;
-    b_base[t] = (t * 32 + lrow) * ST_KS + lh;
-  }
-  f32x16 acc[2][2];
+  for (int t = 0; t < 2; ++t) b_base[t] = (t * 32 + lrow) * ST_KS + lh;
+
+  for (int blk = blockIdx.x; blk < ntiles; blk += gridDim.x) {
+    const long long f = blk / 49;
+    const int lm0 = (blk - (int)f * 49) * 256;    // first output pixel of this tile inside its frame (12544 = 49 * 256)
+    const int oy0 = lm0 / 112;
+    stem_load_patch(xn, patch, f, 2 * oy0 - 3, 13);
+    __syncthreads();
+    int a_base[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-  for (int kh = 0; kh < 7; ++kh)
-#pragma unroll
-    for (int jp = 0; jp < 11; ++jp) {
-      float a[2], b[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) a[t] = patch[a_base[t] + kh * ST_PS + 2 * jp];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) b[t] = wl[b_base[t] + kh * 22 + 2 * jp];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) {
+      const int lm = lm0 + wave * 64 + t * 32 + lrow;
+      const int oy = lm / 112, ox = lm - oy * 112;
+      a_base[t] = 2 * (oy - oy0) * ST_PS + 6 * ox + lh;
     }
-  __syncthreads();
-  gg_epilogue<256, 64, 4, 1, EPI, SMEM>(p, acc, smem, blk * 256, 0, blk);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int jp = 0; jp < 11; ++jp) {
+        float a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = patch[a_base[t] + kh * ST_PS + 2 * jp];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = wl[b_base[t] + kh * 22 + 2 * jp];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+    __syncthreads();
+    gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS>(p, acc, smem, blk * 256, 0, blk);   // ends with a barrier
+  }
 }
 
 int launch_stem_fwd(const float* x_nchw, const float* w147, float* y, float* stats, int F, hipStream_t s) {
@@ -1157,8 +1160,10 @@ int launch_stem_fwd(const float* x_nchw, const float* w147, float* y, float* sta
   p.Hg = 112; p.Wg = 112; p.Ho = 112; p.Wo = 112;
   const double flops = 2.0 * (double)p.M * 64.0 * 147.0;
   prof_begin(KC_GEMM_NARROW, flops, p.M, 64, 147, 1, s);
-  if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS>), dim3(F * 49), dim3(256), 0, s, x_nchw, w147, p);
-  else hipLaunchKernelGGL((stem_fwd_kernel<0>), dim3(F * 49), dim3(256), 0, s, x_nchw, w147, p);
+  const int ntiles = F * 49;
+  const int grid = ntiles < 512 ? ntiles : 512;   // persistent blocks (2 per CU): the 39 KB weight image is staged once per block
+  if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+  else hipLaunchKernelGGL((stem_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
   prof_end(s);
   return check_launch("stem_fwd");
 }
