@@ -22,6 +22,7 @@ from .trainer import Trainer
 from .utils import utils
 from .utils.data_loaders import R3MBuffer, SyntheticBuffer
 from .utils.logger import Logger
+from .utils.prefetch import CudaPrefetcher
 
 
 def make_network(cfg_agent):
@@ -47,7 +48,9 @@ class Workspace:
         else:
             raise NameError('Invalid Dataset')
         mk = lambda it: iter(torch.utils.data.DataLoader(it, batch_size=cfg.batch_size, num_workers=cfg.num_workers, pin_memory=True))  # noqa: E731
-        self.train_loader, self.val_loader = mk(train_it), mk(val_it)
+        # batches are copied to HBM (and cropped, for rc/rctraj) one step ahead on a copy stream
+        self.train_loader = CudaPrefetcher(mk(train_it), self.device, self._gpu_transform(cfg.doaug))
+        self.val_loader = CudaPrefetcher(mk(val_it), self.device, None)
         self.model = make_network(cfg.agent)
         self.timer = utils.Timer()
         self._global_step = 0
@@ -58,12 +61,12 @@ class Workspace:
     def global_step(self):
         return self._global_step
 
-    def _to_device(self, batch_f):
-        x = batch_f.to(self.device, non_blocking=True)
-        if self.cfg.doaug in ("rc", "rctraj"):
+    @staticmethod
+    def _gpu_transform(doaug):
+        if doaug in ("rc", "rctraj"):
             from .augment import random_resized_crop
-            x = random_resized_crop(x, per_clip=(self.cfg.doaug == "rctraj"))
-        return x.float()
+            return lambda x: random_resized_crop(x, per_clip=(doaug == "rctraj"))
+        return None
 
     def train(self):
         train_until_step = utils.Until(self.cfg.train_steps, 1)
@@ -73,7 +76,7 @@ class Workspace:
             t0 = time.time()
             batch_f, batch_langs = next(self.train_loader)
             t1 = time.time()
-            metrics, st = trainer.update(self.model, (self._to_device(batch_f), list(batch_langs)), self.global_step)
+            metrics, st = trainer.update(self.model, (batch_f, list(batch_langs)), self.global_step)
             t2 = time.time()
             self.logger.log_metrics(metrics, self.global_step, ty='train')
             if self.global_step % 10 == 0 and self.rank == 0:
@@ -83,7 +86,7 @@ class Workspace:
             if eval_every_step(self.global_step):
                 with torch.no_grad():
                     batch_f, batch_langs = next(self.val_loader)
-                    metrics, st = trainer.update(self.model, (self._to_device(batch_f), list(batch_langs)), self.global_step, eval=True)
+                    metrics, st = trainer.update(self.model, (batch_f, list(batch_langs)), self.global_step, eval=True)
                     self.logger.log_metrics(metrics, self.global_step, ty='eval')
                     if self.rank == 0:
                         print("EVAL", self.global_step, metrics)

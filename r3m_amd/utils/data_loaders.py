@@ -3,7 +3,8 @@
 R3MBuffer mirrors the Ego4D sampler of /root/reference/r3m/utils/data_loaders.py:38-109 (frame-index sampling at :66-79 and
 the rc / rctraj crop semantics at :81-102) but decodes with PIL instead of torchvision.io and leaves the crop to the GPU
 (r3m_amd/augment.py); SyntheticBuffer yields seeded random clips of the same shape for bring-up, tests and bench.
-Each item: (frames [5,3,224,224] float32 in 0..255 ordered (start, goal, s0, s1, s2), label:str)."""
+Each item: (frames [5,3,H,W] uint8 ordered (start, goal, s0, s1, s2), label:str); the training loop casts to float32 0..255
+(the encoder's input convention) on the GPU."""
 import random
 
 import numpy as np
@@ -20,7 +21,7 @@ class SyntheticBuffer(IterableDataset):
         info = torch.utils.data.get_worker_info()
         g = torch.Generator().manual_seed(self.seed + (info.id if info else 0) * 7919)
         while True:
-            im = torch.randint(0, 256, (5, 3, 224, 224), generator=g).float()
+            im = torch.randint(0, 256, (5, 3, 224, 224), generator=g, dtype=torch.uint8)   # uint8 over PCIe, float on the GPU
             label = self.labels[int(torch.randint(0, len(self.labels), (1,), generator=g))]
             yield im, label
 
@@ -61,7 +62,7 @@ class R3MBuffer(IterableDataset):
         vidlen, txt, vid = m["len"], m["txt"], m["path"]
         label = txt[2:]   # cuts off the "C " prefix (data_loaders.py:69)
         idx = sample_indices(vidlen, self.alpha)
-        im = torch.stack([self._read(vid, i) for i in idx]).float()
+        im = torch.stack([self._read(vid, i) for i in idx])   # uint8 [5,3,H,W]; cast / crop happen on the GPU
         return im, label
 
     def __iter__(self):

@@ -168,3 +168,29 @@ def test_encoder_large_batch_properties(hip):
     assert torch.equal(h1, h2)                      # bit-reproducible
     assert (h1 >= 0).all()                          # avg-pool of ReLU
     torch.testing.assert_close(h1[8:24], h3, rtol=1e-5, atol=1e-6)   # eval-mode frames are independent
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_small_ragged_batches_vs_oracle(hip, B):
+    """Edge sizes: a single clip (every permutation is the identity: negatives at distance 0, sub-gradient 0) and an odd
+    batch (5B frames not a multiple of any tile size) — one full step against the CPU oracle."""
+    from oracle import detgen, r3m_ref
+    from r3m_amd import R3M
+    from r3m_amd.parallel import SingleDevice
+    from r3m_amd.trainer import Trainer
+    m = R3M("cuda", 1e-4, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    _load_state(m.convnet)
+    ref = r3m_ref.R3MRef(size=18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    ref.convnet.load_state_dict({k: v.cpu() for k, v in m.convnet.state_dict().items()})
+    model = SingleDevice(m).to(DEV)
+    frames = torch.from_numpy(detgen.frames(f"ragged{B}", (B, 5, 3, 224, 224)))
+    torch.manual_seed(11)
+    perms = torch.stack([torch.randperm(B) for _ in range(6)])
+    torch.manual_seed(11)
+    metrics, _ = Trainer(1).update(model, (frames.to(DEV), [""] * B), 0)
+    mref = r3m_ref.train_step_ref(ref, frames, tcn_perm=perms)
+    for k, v in mref.items():
+        assert abs(metrics[k] - v) <= 2e-4 * max(1.0, abs(v)), (B, k, metrics[k], v)
+    assert all(np.isfinite(v) for v in metrics.values())
+    sd = m.convnet.state_dict()
+    assert torch.isfinite(sd["conv1.weight"]).all() and int(sd["bn1.num_batches_tracked"]) == 1
