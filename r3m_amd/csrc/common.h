@@ -74,6 +74,7 @@ struct WgradParams {
   int rows_per_split;  // multiple of 32
   int simple_rows;     // 1x1 stride-1: X row offset = m*Ci
   int tilesN;          // ceil(Ci / BN)
+  int interleave;      // 1: spread the next K step's DMA pieces between this step's MFMAs (set by the launcher)
 };
 
 // ---- launchers (conv.hip) ----
