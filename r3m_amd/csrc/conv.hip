@@ -957,7 +957,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 template <int BMt, int BNt>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BK = 32;
-  constexpr int TM = BMt / 64, TN = BNt / 64;
+  // 128x128: waves 1 x 4, each 128 (co, interleaved: MFMA tile tm owns channels 4*i + tm) x 32 (ci) -> the A fragment of all
+  // four tiles is ONE ds_read_b128 per K pair; 64x64: waves 2 x 2, each 32 x 32.
+  constexpr bool WIDE = (BMt == 128);
+  constexpr int TM = WIDE ? 4 : BMt / 64, TN = WIDE ? 1 : BNt / 64;
   constexpr int A_RPI = 256 / BMt, B_RPI = 256 / BNt;   // k rows covered by one 1 KiB DMA instruction
   constexpr int AJ = 8 / A_RPI, BJ = 8 / B_RPI;         // instructions per wave per stage (8 k rows per wave)
   constexpr int STAGE = BK * (BMt + BNt);
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave_s >> 1, wn = wave_s & 1;
+  const int wm = WIDE ? 0 : (wave_s >> 1), wn = WIDE ? wave_s : (wave_s & 1);
   const int T = p.KH * p.KW;
   const int tap = blockIdx.x % T;
   const int tile = blockIdx.x / T;
@@ -1077,7 +1080,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int lrow = lane & 31, lh = lane >> 5;
-  const float* fragA = smem + lh * BMt + wm * TM * 32 + lrow;
+  const float* fragA = smem + lh * BMt + (WIDE ? 4 * lrow : wm * TM * 32 + lrow);
   const float* fragB = smem + BK * BMt + lh * BNt + wn * TN * 32 + lrow;
   // MFMAs of one stage; when dma_stage >= 0 the next K step's DMA pieces are spread between them (one piece per
   // 16/(AJ+BJ) K pairs) so that their issue cost hides behind this wave's own MFMAs
@@ -1087,8 +1090,14 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
     static_for<BK / 2>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
       float a[TM], b[TN];
+      if constexpr (WIDE) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(fa + kk * 2 * BMt);
 #pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = fa[kk * 2 * BMt + t * 32];
+        for (int t = 0; t < TM; ++t) a[t] = a4[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = fa[kk * 2 * BMt + t * 32];
+      }
 #pragma unroll
       for (int t = 0; t < TN; ++t) b[t] = fb[kk * 2 * BNt + t * 32];
 #pragma unroll
@@ -1138,7 +1147,8 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int co = WIDE ? co0 + 4 * rho + tm : co0 + (wm * TM + tm) * 32 + rho;
       if (co >= p.Co) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
