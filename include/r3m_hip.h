@@ -107,6 +107,41 @@ int r3m_maxpool_bwd(const float* dp, const unsigned char* argmax, float* dz, int
 int r3m_avgpool_fwd(const float* x, float* h, int N, int HW, int C, r3m_stream_t stream);
 int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream_t stream);
 
+/* ---------------- mixed precision: bf16 activations (BASELINE configs[2], [4]) -------------------------------------
+ * The `_dt` variants take `dtype`: R3M_DT_F32 (identical to the plain entry points above) or R3M_DT_BF16. With bf16 every
+ * ACTIVATION tensor (x, y, z, r, dy, dz, dx, dp ...) is NHWC bfloat16; what stays fp32: master weights, weight / BatchNorm
+ * gradients, BatchNorm statistics partials and coefficients, the stem's normalised input xn, the embedding h / dh, and all
+ * accumulation (v_mfma_f32_32x32x16_bf16). This is the counterpart of running the reference's encoder call
+ * (r3m/models/models_r3m.py:99, backward at r3m/trainer.py:157) under torch.autocast(bfloat16); the reference itself is
+ * fp32 only. Channel counts must be multiples of 64 (every ResNet-18/34/50 layer behind the stem is).
+ *   r3m_conv2d_fwd_dt    w: bf16 [Co][k][k][Ci] for R3M_DT_BF16 (make it with r3m_convert_bf16 from the fp32 master)
+ *   r3m_conv2d_dgrad_dt  w: the fp32 master [Co][k][k][Ci] (transposed + converted into the workspace)
+ *   r3m_conv2d_wgrad_dt  dw: fp32 */
+enum { R3M_DT_F32 = 0, R3M_DT_BF16 = 1 };
+r3m_resnet_t r3m_resnet_create_dt(int size /*18|34|50*/, int frames, int dtype);
+int r3m_resnet_dtype(r3m_resnet_t h);
+int r3m_convert_bf16(const float* src, void* dst_bf16, long long n /* multiple of 4 */, r3m_stream_t stream);
+int r3m_conv2d_fwd_dt(const void* x, const void* w_ohwi, void* y, float* stats, int N, int Hi, int Wi, int Ci, int Co, int k,
+                      int stride, int pad, int dtype, r3m_stream_t stream);
+int r3m_conv2d_dgrad_dt(const void* dy, const float* w_ohwi, void* dx, void* workspace, size_t workspace_bytes, int N, int Hi,
+                        int Wi, int Ci, int Co, int k, int stride, int pad, int dtype, r3m_stream_t stream);
+size_t r3m_conv2d_wgrad_workspace_bytes_dt(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dtype);
+int r3m_conv2d_wgrad_dt(const void* x, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int N, int Hi,
+                        int Wi, int Ci, int Co, int k, int stride, int pad, int accumulate, int dtype, r3m_stream_t stream);
+int r3m_stem_conv_fwd_dt(const float* xn, const float* w_ohwi, void* y, float* stats, int frames, int dtype, r3m_stream_t stream);
+int r3m_stem_conv_wgrad_dt(const float* xn, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int frames,
+                           int accumulate, int dtype, r3m_stream_t stream);
+int r3m_bn_act_fwd_dt(const void* y, const float* coef, const void* r, const void* y2, const float* coef2, void* z,
+                      long long rows, int C, int relu, unsigned* maskbits, int dtype, r3m_stream_t stream);
+int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, const void* y, const float* coef, float* dgamma,
+                  float* dbeta, void* dy, void* workspace, size_t workspace_bytes, long long rows, int C, int use_batch_stats,
+                  int accumulate, int dtype, r3m_stream_t stream);
+int r3m_maxpool_fwd_dt(const void* z, void* p, unsigned char* argmax, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream);
+int r3m_maxpool_bwd_dt(const void* dp, const unsigned char* argmax, void* dz, int N, int Hi, int Wi, int C, int dtype,
+                       r3m_stream_t stream);
+int r3m_avgpool_fwd_dt(const void* x, float* h, int N, int HW, int C, int dtype, r3m_stream_t stream);
+int r3m_avgpool_bwd_dt(const float* dh, void* dx, int N, int HW, int C, int dtype, r3m_stream_t stream);
+
 /* nn.Linear (+ReLU) of LanguageReward.pred (r3m/models/models_language.py:43-51): y[M,N] = x[M,K] w[N,K]^T + b */
 int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu,
                    r3m_stream_t stream);

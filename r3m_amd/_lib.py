@@ -58,6 +58,21 @@ SIGNATURES = {
     "r3m_maxpool_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_avgpool_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     "r3m_avgpool_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    "r3m_resnet_create_dt": (C.c_void_p, [c_i, c_i, c_i]),
+    "r3m_resnet_dtype": (c_i, [C.c_void_p]),
+    "r3m_convert_bf16": (c_i, [c_f, c_f, c_ll, c_f]),
+    "r3m_conv2d_fwd_dt": (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 9 + [c_f]),
+    "r3m_conv2d_dgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 9 + [c_f]),
+    "r3m_conv2d_wgrad_workspace_bytes_dt": (c_sz, [c_i] * 9),
+    "r3m_conv2d_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 10 + [c_f]),
+    "r3m_stem_conv_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
+    "r3m_stem_conv_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_f]),
+    "r3m_bn_act_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f, c_i, c_f]),
+    "r3m_bn_bwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_maxpool_fwd_dt": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_maxpool_bwd_dt": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_avgpool_fwd_dt": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_avgpool_bwd_dt": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_linear_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_crop_resize": (c_i, [c_f, c_i, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_num_params": (c_ll, [c_i, c_i, c_i]),

@@ -8,11 +8,21 @@
 //   statistics: the conv epilogue (conv.hip EPI_STATS) leaves fp32 per-row-block sum / sum-of-squares, which are
 //   combined here in fp64, so E[y^2] - mean^2 is evaluated without fp32 cancellation.
 #include "common.h"
+#include "conv_dev.h"
 
 namespace r3m {
 
+// activations are float or bf16_t (T); per-channel coefficients, statistics and partial sums are always fp32
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// dispatch a templated kernel launch on the activation storage type
+#define DT_DISPATCH(dt, NAME, ...)                                        \
+  do {                                                                    \
+    if ((dt) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; }               \
+    else if ((dt) == DT_F32) { typedef float T; __VA_ARGS__; }            \
+    else { set_last_error(NAME ": unknown dtype %d", (int)(dt)); return 1; } \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // partials [rows][2][C] (fp32)  ->  acc [S][2][C] (fp64), S = gridDim.y slices, fixed order inside a slice
@@ -122,26 +132,26 @@ int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* ru
 //   R      : identity branch (already activated block input)
 //   Y2,... : downsample branch raw conv output with its own BatchNorm coefficients
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE>  // 0: plain, 1: + R, 2: + affine(Y2)
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, const float* __restrict__ R,
+template <int MODE, class T>  // 0: plain, 1: + R, 2: + affine(Y2)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const T* __restrict__ R,
                                                           const float* __restrict__ scale2, const float* __restrict__ shift2,
-                                                          float* __restrict__ Z, long long n4, int c4mask, int relu,
+                                                          T* __restrict__ Z, long long n4, int c4mask, int relu,
                                                           unsigned* __restrict__ maskbits) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;   // n4 is a multiple of 8 when maskbits is used: an 8-lane nibble group is all in or all out
   const int c = ((int)(i & c4mask)) * 4;
-  const f32x4 y = ld4(Y + i * 4);
+  const f32x4 y = ld4t(Y + i * 4);
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
   f32x4 z;
 #pragma unroll
   for (int e = 0; e < 4; ++e) z[e] = fmaf(y[e], sc[e], sh[e]);
   if (MODE == 1) {
-    const f32x4 r = ld4(R + i * 4);
+    const f32x4 r = ld4t(R + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] += r[e];
   } else if (MODE == 2) {
-    const f32x4 y2 = ld4(R + i * 4);
+    const f32x4 y2 = ld4t(R + i * 4);
     const f32x4 sc2 = ld4(scale2 + c), sh2 = ld4(shift2 + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] += fmaf(y2[e], sc2[e], sh2[e]);
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] = fmaxf(z[e], 0.f);
   }
-  st4(Z + i * 4, z);
+  st4t(Z + i * 4, z);
   if (maskbits) {
     // ReLU mask of the stored activation, 1 bit per element: float4 index i owns nibble (i & 7) of word i >> 3. The
     // backward kernels read this (1/32 of the bytes) instead of re-reading the activation just to test z > 0.
@@ -163,19 +173,24 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
-int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
-                      const float* shift2, float* Z, long long rows, int C, int relu, unsigned* maskbits, hipStream_t s) {
+int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, const void* Rv, const float* scale2,
+                      const float* shift2, void* Zv, long long rows, int C, int relu, unsigned* maskbits, int dt, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_act_fwd: C=%d must be a power of two >= 4", C);
   R3M_REQUIRE(!maskbits || (rows * C / 4) % 8 == 0, "bn_act_fwd: bit mask needs rows*C to be a multiple of 32");
   const long long n4 = rows * C / 4;
   const int grid = ceil_div(n4, 256);
   const int c4mask = C / 4 - 1;
-  if (R && scale2)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<2>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
-  else if (R)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<1>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
-  else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+  DT_DISPATCH(dt, "bn_act_fwd", {
+    const T* Y = static_cast<const T*>(Yv);
+    const T* R = static_cast<const T*>(Rv);
+    T* Z = static_cast<T*>(Zv);
+    if (R && scale2)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<2, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+    else if (R)
+      hipLaunchKernelGGL((bn_act_fwd_kernel<1, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+    else
+      hipLaunchKernelGGL((bn_act_fwd_kernel<0, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+  });
   return check_launch("bn_act_fwd");
 }
 
@@ -190,8 +205,9 @@ __device__ __forceinline__ unsigned mask_nibble(const unsigned* bits, long long 
   return (bits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
-                                                             const unsigned* __restrict__ Zbits, const float* __restrict__ Y, const float* __restrict__ scale,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dZ, const T* __restrict__ Zmask,
+                                                             const unsigned* __restrict__ Zbits, const T* __restrict__ Y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, float* __restrict__ partials,
                                                              long long rows, int C, int cpb4, int rows_per_block) {
@@ -206,15 +222,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   for (long long r = r_begin + trow; r < r_end; r += rpp) {
     const long long off = r * C + c;
-    const f32x4 y = ld4(Y + off);
-    const f32x4 dz = ld4(dZ + off);
+    const f32x4 y = ld4t(Y + off);
+    const f32x4 dz = ld4t(dZ + off);
     f32x4 g;
     if (Zbits) {
       const unsigned nb = mask_nibble(Zbits, off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = ((nb >> e) & 1u) ? dz[e] : 0.f;
     } else if (Zmask) {
-      const f32x4 z = ld4(Zmask + off);
+      const f32x4 z = ld4t(Zmask + off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
     } else {
@@ -254,14 +270,16 @@ int bn_bwd_partial_rows(long long rows, int C) {
   return nblk;
 }
 
-int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
-                         hipStream_t s) {
+                         int dt, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce: C=%d must be a power of two >= 4", C);
   int cpb4, rpb, nblk;
   bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s, dZ, Zmask, Zbits, Y, scale,
-                     shift, mean, invstd, partials, rows, C, cpb4, rpb);
+  DT_DISPATCH(dt, "bn_bwd_reduce",
+              hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s,
+                                 static_cast<const T*>(dZ), static_cast<const T*>(Zmask), Zbits, static_cast<const T*>(Y), scale,
+                                 shift, mean, invstd, partials, rows, C, cpb4, rpb));
   return check_launch("bn_bwd_reduce");
 }
 
@@ -291,17 +309,18 @@ int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long coun
 }
 
 // pass 2:  dY = scale * (g - c1 - yhat * c2)       (c1 = mean(g), c2 = mean(g*yhat); both 0 in eval mode)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dZ, const float* __restrict__ Zmask,
-                                                            const unsigned* __restrict__ Zbits, const float* __restrict__ Y, const float* __restrict__ scale,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dZ, const T* __restrict__ Zmask,
+                                                            const unsigned* __restrict__ Zbits, const T* __restrict__ Y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ c1,
-                                                            const float* __restrict__ c2, float* __restrict__ dY,
+                                                            const float* __restrict__ c2, T* __restrict__ dY,
                                                             long long n4, int c4mask) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int c = ((int)(i & c4mask)) * 4;
-  const f32x4 y = ld4(Y + i * 4);
-  const f32x4 dz = ld4(dZ + i * 4);
+  const f32x4 y = ld4t(Y + i * 4);
+  const f32x4 dz = ld4t(dZ + i * 4);
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
   f32x4 g;
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = ((nb >> e) & 1u) ? dz[e] : 0.f;
   } else if (Zmask) {
-    const f32x4 z = ld4(Zmask + i * 4);
+    const f32x4 z = ld4t(Zmask + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? dz[e] : 0.f;
   } else {
@@ -323,16 +342,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float yh = (y[e] - mu[e]) * is[e];
     o[e] = sc[e] * (g[e] - k1[e] - yh * k2[e]);
   }
-  st4(dY + i * 4, o);
+  st4t(dY + i * 4, o);
 }
 
-int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
-                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
-                        long long rows, int C, hipStream_t s) {
+int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dY,
+                        long long rows, int C, int dt, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_apply: C=%d must be a power of two >= 4", C);
   const long long n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, dZ, Zmask, Zbits, Y, scale, shift,
-                     mean, invstd, c1, c2, dY, n4, C / 4 - 1);
+  DT_DISPATCH(dt, "bn_bwd_apply",
+              hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, static_cast<const T*>(dZ),
+                                 static_cast<const T*>(Zmask), Zbits, static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2,
+                                 static_cast<T*>(dY), n4, C / 4 - 1));
   return check_launch("bn_bwd_apply");
 }
 
@@ -341,7 +362,8 @@ int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const unsigned* Zbi
 // row-major scan order, like ATen) in one byte per output element; backward is a gather over the <= 4 windows that
 // contain an input pixel, so it needs neither atomics nor a zero-fill pass.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ Z, float* __restrict__ P,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ Z, T* __restrict__ P,
                                                            unsigned char* __restrict__ amax, long long total, int Hi, int Wi,
                                                            int Ho, int Wo, int C4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -362,26 +384,29 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     for (int j = 0; j < 3; ++j) {
       const int x = px * 2 - 1 + j;
       if ((unsigned)x >= (unsigned)Wi) continue;
-      const f32x4 v = ld4(Z + (((n * Hi + y) * Wi + x) * C4 + c4) * 4);
+      const f32x4 v = ld4t(Z + (((n * Hi + y) * Wi + x) * C4 + c4) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = i * 3 + j; }
       first = false;
     }
   }
-  st4(P + idx * 4, best);
+  st4t(P + idx * 4, best);
   *reinterpret_cast<uchar4*>(amax + idx * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
 }
 
-int launch_maxpool_fwd(const float* Z, float* P, unsigned char* amax, int N, int Hi, int Wi, int C, hipStream_t s) {
+int launch_maxpool_fwd(const void* Z, void* P, unsigned char* amax, int N, int Hi, int Wi, int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
   const long long total = (long long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, Z, P, amax, total, Hi, Wi, Ho, Wo, C / 4);
+  DT_DISPATCH(dt, "maxpool_fwd",
+              hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(Z),
+                                 static_cast<T*>(P), amax, total, Hi, Wi, Ho, Wo, C / 4));
   return check_launch("maxpool_fwd");
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dP, const unsigned char* __restrict__ amax,
-                                                           float* __restrict__ dZ, long long total, int Hi, int Wi, int Ho,
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                           T* __restrict__ dZ, long long total, int Hi, int Wi, int Ho,
                                                            int Wo, int C4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -403,47 +428,52 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
       const int code = i * 3 + j;
       const long long o = (((n * Ho + py) * Wo + px) * C4 + c4) * 4;
       const uchar4 a = *reinterpret_cast<const uchar4*>(amax + o);
-      const f32x4 d = ld4(dP + o);
+      const f32x4 d = ld4t(dP + o);
       if (a.x == code) g[0] += d[0];
       if (a.y == code) g[1] += d[1];
       if (a.z == code) g[2] += d[2];
       if (a.w == code) g[3] += d[3];
     }
   }
-  st4(dZ + idx * 4, g);
+  st4t(dZ + idx * 4, g);
 }
 
-int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, int N, int Hi, int Wi, int C, hipStream_t s) {
+int launch_maxpool_bwd(const void* dP, const unsigned char* amax, void* dZ, int N, int Hi, int Wi, int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
   const long long total = (long long)N * Hi * Wi * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dP, amax, dZ, total, Hi, Wi, Ho, Wo, C / 4);
+  DT_DISPATCH(dt, "maxpool_bwd",
+              hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(dP), amax,
+                                 static_cast<T*>(dZ), total, Hi, Wi, Ho, Wo, C / 4));
   return check_launch("maxpool_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // AdaptiveAvgPool2d(1) + flatten: [N, HW, C] -> [N, C]  and its backward (broadcast of dH / HW)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ X, float* __restrict__ H, long long total,
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ X, float* __restrict__ H, long long total,
                                                            int HW, int C4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c4 = (int)(idx % C4);
   const long long n = idx / C4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < HW; ++p) s += ld4(X + ((n * HW + p) * C4 + c4) * 4);
+  for (int p = 0; p < HW; ++p) s += ld4t(X + ((n * HW + p) * C4 + c4) * 4);
   const float d = (float)HW;
 #pragma unroll
   for (int e = 0; e < 4; ++e) s[e] = s[e] / d;
   st4(H + idx * 4, s);
 }
 
-int launch_avgpool_fwd(const float* X, float* H, int N, int HW, int C, hipStream_t s) {
+int launch_avgpool_fwd(const void* X, float* H, int N, int HW, int C, int dt, hipStream_t s) {
   const long long total = (long long)N * (C / 4);
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, X, H, total, HW, C / 4);
+  DT_DISPATCH(dt, "avgpool_fwd",
+              hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(X), H, total, HW, C / 4));
   return check_launch("avgpool_fwd");
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dH, float* __restrict__ dX, long long total,
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dH, T* __restrict__ dX, long long total,
                                                            int HW, int C4) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -453,12 +483,13 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   const float d = (float)HW;
 #pragma unroll
   for (int e = 0; e < 4; ++e) g[e] = g[e] / d;
-  st4(dX + idx * 4, g);
+  st4t(dX + idx * 4, g);
 }
 
-int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStream_t s) {
+int launch_avgpool_bwd(const float* dH, void* dX, int N, int HW, int C, int dt, hipStream_t s) {
   const long long total = (long long)N * HW * (C / 4);
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, dH, dX, total, HW, C / 4);
+  DT_DISPATCH(dt, "avgpool_bwd",
+              hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, dH, static_cast<T*>(dX), total, HW, C / 4));
   return check_launch("avgpool_bwd");
 }
 

@@ -8,15 +8,16 @@ OBJ="$HERE/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
-for f in conv bn loss adam lang augment engine capi; do
+SRCS="conv conv_bf16 bn loss adam lang augment engine capi"
+for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/r3m_hip.h" -nt "$OBJ/$f.o" ]; then
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/conv_dev.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/r3m_hip.h" -nt "$OBJ/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=()
-for f in conv bn loss adam lang augment engine capi; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
+for f in $SRCS; do [ -f "$OBJ/$f.o" ] && objs+=("$OBJ/$f.o"); done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libr3m_hip.so" "${objs[@]}"
 echo "built $OUT/libr3m_hip.so"

@@ -70,18 +70,19 @@ void prof_end(hipStream_t s) {
 int debug_occupancy(int* out4);
 // engine.hip
 struct Plan;
-Plan* plan_create(int size, int F);
+Plan* plan_create(int size, int F, int dtype);
+int plan_dtype(Plan*);
 int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
                  hipStream_t s);
 int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
                   int accumulate, int* gd_io, hipStream_t s);
 int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
-                        int Co, int k, int stride, int pad, int flags, hipStream_t s);
+                        int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s);
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
-                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s);
 int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
-                      int stride, int pad, int accumulate, hipStream_t s);
-size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
+                      int stride, int pad, int accumulate, int dt, hipStream_t s);
+size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dt);
 // accessors implemented in engine.hip
 int plan_out_dim(Plan*);
 long long plan_num_params(Plan*);
@@ -152,7 +153,9 @@ int r3m_profile_collect(double* ms, long long* launches, double* flops) {
 }
 const char* r3m_last_error(void) { return g_err; }
 
-r3m_resnet_t r3m_resnet_create(int size, int frames) { return reinterpret_cast<r3m_resnet_t>(plan_create(size, frames)); }
+r3m_resnet_t r3m_resnet_create(int size, int frames) { return reinterpret_cast<r3m_resnet_t>(plan_create(size, frames, DT_F32)); }
+r3m_resnet_t r3m_resnet_create_dt(int size, int frames, int dtype) { return reinterpret_cast<r3m_resnet_t>(plan_create(size, frames, dtype)); }
+int r3m_resnet_dtype(r3m_resnet_t h) { return plan_dtype(PLAN(h)); }
 void r3m_resnet_destroy(r3m_resnet_t h) { if (h) plan_destroy(PLAN(h)); }
 int r3m_resnet_out_dim(r3m_resnet_t h) { return plan_out_dim(PLAN(h)); }
 long long r3m_resnet_num_params(r3m_resnet_t h) { return plan_num_params(PLAN(h)); }
@@ -182,41 +185,79 @@ int r3m_conv2d_stats_rows(int N, int Hi, int Wi, int Co, int k, int stride, int 
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   return gather_gemm_grid_m(N * Ho * Wo, Co);
 }
+static int check_dt(int dtype, const char* what) {
+  R3M_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "%s: dtype %d (0 = fp32, 1 = bf16)", what, dtype);
+  return 0;
+}
+#define FP(x) static_cast<const float*>(x)
+#define FPM(x) static_cast<float*>(x)
+int r3m_convert_bf16(const float* src, void* dst, long long n, r3m_stream_t stream) {
+  R3M_REQUIRE(src && dst, "convert_bf16: null argument");
+  return launch_convert_bf16(src, dst, n, S(stream));
+}
+int r3m_conv2d_fwd_dt(const void* x, const void* w, void* y, float* stats, int N, int Hi, int Wi, int Ci, int Co, int k, int stride,
+                      int pad, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "conv2d_fwd")) return 1;
+  return conv_forward_launch(FP(x), FP(w), FPM(y), stats, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, stats ? EPI_STATS : 0, dtype, S(stream));
+}
 int r3m_conv2d_fwd(const float* x, const float* w, float* y, float* stats, int N, int Hi, int Wi, int Ci, int Co, int k, int stride,
                    int pad, r3m_stream_t stream) {
-  return conv_forward_launch(x, w, y, stats, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, stats ? EPI_STATS : 0, S(stream));
+  return r3m_conv2d_fwd_dt(x, w, y, stats, N, Hi, Wi, Ci, Co, k, stride, pad, DT_F32, stream);
 }
 size_t r3m_conv2d_dgrad_workspace_bytes(int Ci, int Co, int k) { return (size_t)Ci * Co * k * k * 4; }
-int r3m_conv2d_dgrad(const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
-                     int k, int stride, int pad, r3m_stream_t stream) {
+int r3m_conv2d_dgrad_dt(const void* dy, const float* w, void* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                        int k, int stride, int pad, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "conv2d_dgrad")) return 1;
   R3M_REQUIRE(ws_bytes >= r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k), "conv2d_dgrad: workspace too small");
   float* Wt = static_cast<float*>(ws);
-  if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
-  return conv_dgrad_launch(dy, Wt, dx, nullptr, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, S(stream));
+  if (dtype == DT_BF16) { if (int e = launch_transpose_w_bf16(w, Wt, Co, k * k, Ci, S(stream))) return e; }
+  else if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
+  return conv_dgrad_launch(FP(dy), Wt, FPM(dx), nullptr, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, dtype, S(stream));
+}
+int r3m_conv2d_dgrad(const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                     int k, int stride, int pad, r3m_stream_t stream) {
+  return r3m_conv2d_dgrad_dt(dy, w, dx, ws, ws_bytes, N, Hi, Wi, Ci, Co, k, stride, pad, DT_F32, stream);
+}
+size_t r3m_conv2d_wgrad_workspace_bytes_dt(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dtype) {
+  return conv_wgrad_ws_floats(N, Hi, Wi, Ci, Co, k, stride, pad, dtype) * 4;
 }
 size_t r3m_conv2d_wgrad_workspace_bytes(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
-  return conv_wgrad_ws_floats(N, Hi, Wi, Ci, Co, k, stride, pad) * 4;
+  return r3m_conv2d_wgrad_workspace_bytes_dt(N, Hi, Wi, Ci, Co, k, stride, pad, DT_F32);
+}
+int r3m_conv2d_wgrad_dt(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                        int k, int stride, int pad, int accumulate, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "conv2d_wgrad")) return 1;
+  R3M_REQUIRE(ws_bytes >= r3m_conv2d_wgrad_workspace_bytes_dt(N, Hi, Wi, Ci, Co, k, stride, pad, dtype), "conv2d_wgrad: workspace too small");
+  return conv_wgrad_launch(FP(x), FP(dy), dw, static_cast<float*>(ws), N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, dtype, S(stream));
 }
 int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
                      int k, int stride, int pad, int accumulate, r3m_stream_t stream) {
-  R3M_REQUIRE(ws_bytes >= r3m_conv2d_wgrad_workspace_bytes(N, Hi, Wi, Ci, Co, k, stride, pad), "conv2d_wgrad: workspace too small");
-  return conv_wgrad_launch(x, dy, dw, static_cast<float*>(ws), N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, S(stream));
+  return r3m_conv2d_wgrad_dt(x, dy, dw, ws, ws_bytes, N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, DT_F32, stream);
 }
 int r3m_stem_im2col(const float* x, float* col, int frames, r3m_stream_t stream) { return launch_stem_im2col(x, col, frames, S(stream)); }
 int r3m_stem_prep(const float* x, float* xn, int frames, r3m_stream_t stream) {
   R3M_REQUIRE(x && xn, "stem_prep: null argument");
   return launch_stem_prep(x, xn, frames, S(stream));
 }
-int r3m_stem_conv_fwd(const float* xn, const float* w_ohwi, float* y, float* stats, int frames, r3m_stream_t stream) {
+int r3m_stem_conv_fwd_dt(const float* xn, const float* w_ohwi, void* y, float* stats, int frames, int dtype, r3m_stream_t stream) {
   R3M_REQUIRE(xn && w_ohwi && y, "stem_conv_fwd: null argument");
-  return launch_stem_fwd(xn, w_ohwi, y, stats, frames, S(stream));
+  if (check_dt(dtype, "stem_conv_fwd")) return 1;
+  return launch_stem_fwd(xn, w_ohwi, y, stats, frames, dtype, S(stream));
+}
+int r3m_stem_conv_fwd(const float* xn, const float* w_ohwi, float* y, float* stats, int frames, r3m_stream_t stream) {
+  return r3m_stem_conv_fwd_dt(xn, w_ohwi, y, stats, frames, DT_F32, stream);
 }
 size_t r3m_stem_conv_wgrad_workspace_bytes(void) { return (stem_wgrad_ws_floats() + 64 * 160) * 4; }
+int r3m_stem_conv_wgrad_dt(const float* xn, const void* dy, float* dw_ohwi, void* ws, size_t ws_bytes, int frames, int accumulate,
+                           int dtype, r3m_stream_t stream) {
+  R3M_REQUIRE(xn && dy && dw_ohwi && ws, "stem_conv_wgrad: null argument");
+  if (check_dt(dtype, "stem_conv_wgrad")) return 1;
+  R3M_REQUIRE(ws_bytes >= r3m_stem_conv_wgrad_workspace_bytes(), "stem_conv_wgrad: workspace too small");
+  return launch_stem_wgrad(xn, dy, dw_ohwi, static_cast<float*>(ws), frames, accumulate, dtype, S(stream));
+}
 int r3m_stem_conv_wgrad(const float* xn, const float* dy, float* dw_ohwi, void* ws, size_t ws_bytes, int frames, int accumulate,
                         r3m_stream_t stream) {
-  R3M_REQUIRE(xn && dy && dw_ohwi && ws, "stem_conv_wgrad: null argument");
-  R3M_REQUIRE(ws_bytes >= r3m_stem_conv_wgrad_workspace_bytes(), "stem_conv_wgrad: workspace too small");
-  return launch_stem_wgrad(xn, dy, dw_ohwi, static_cast<float*>(ws), frames, accumulate, S(stream));
+  return r3m_stem_conv_wgrad_dt(xn, dy, dw_ohwi, ws, ws_bytes, frames, accumulate, DT_F32, stream);
 }
 
 // workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
@@ -239,36 +280,63 @@ int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, c
                        r3m_stream_t stream) {
   return launch_bn_eval_coeffs(gamma, beta, rm, rv, eps, coef, coef + C, coef + 2 * C, coef + 3 * C, C, S(stream));
 }
+int r3m_bn_act_fwd_dt(const void* y, const float* coef, const void* r, const void* y2, const float* coef2, void* z, long long rows,
+                      int C, int relu, unsigned* maskbits, int dtype, r3m_stream_t stream) {
+  R3M_REQUIRE(!(r && y2), "bn_act_fwd: pass either r (identity) or y2/coef2 (downsample), not both");
+  if (check_dt(dtype, "bn_act_fwd")) return 1;
+  if (y2) return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, y2, coef2 + 2 * C, coef2 + 3 * C, z, rows, C, relu, maskbits, dtype, S(stream));
+  return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, r, nullptr, nullptr, z, rows, C, relu, maskbits, dtype, S(stream));
+}
 int r3m_bn_act_fwd(const float* y, const float* coef, const float* r, const float* y2, const float* coef2, float* z, long long rows,
                    int C, int relu, unsigned* maskbits, r3m_stream_t stream) {
-  R3M_REQUIRE(!(r && y2), "bn_act_fwd: pass either r (identity) or y2/coef2 (downsample), not both");
-  if (y2) return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, y2, coef2 + 2 * C, coef2 + 3 * C, z, rows, C, relu, maskbits, S(stream));
-  return launch_bn_act_fwd(y, coef + 2 * C, coef + 3 * C, r, nullptr, nullptr, z, rows, C, relu, maskbits, S(stream));
+  return r3m_bn_act_fwd_dt(y, coef, r, y2, coef2, z, rows, C, relu, maskbits, DT_F32, stream);
 }
-int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const float* y, const float* coef, float* dgamma,
-               float* dbeta, float* dy, void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
+int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, const void* y, const float* coef, float* dgamma,
+                  float* dbeta, void* dy, void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate,
+                  int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "bn_bwd")) return 1;
   R3M_REQUIRE(ws_bytes >= r3m_bn_workspace_bytes(rows, C), "bn_bwd: workspace too small (need %zu)", r3m_bn_workspace_bytes(rows, C));
   float* partial = static_cast<float*>(ws);
   double* acc = reinterpret_cast<double*>(static_cast<char*>(ws) + bn_acc_off(rows, C));
   float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
-  if (int e = launch_bn_bwd_reduce(dz, zmask, zbits, y, scale, shift, mean, invstd, partial, rows, C, S(stream))) return e;
+  if (int e = launch_bn_bwd_reduce(dz, zmask, zbits, y, scale, shift, mean, invstd, partial, rows, C, dtype, S(stream))) return e;
   const int prow = bn_bwd_partial_rows(rows, C);
   if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
   if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
-  return launch_bn_bwd_apply(dz, zmask, zbits, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, S(stream));
+  return launch_bn_bwd_apply(dz, zmask, zbits, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, dtype, S(stream));
+}
+int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const float* y, const float* coef, float* dgamma,
+               float* dbeta, float* dy, void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
+  return r3m_bn_bwd_dt(dz, zmask, zbits, y, coef, dgamma, dbeta, dy, ws, ws_bytes, rows, C, use_batch_stats, accumulate, DT_F32, stream);
+}
+int r3m_maxpool_fwd_dt(const void* z, void* p, unsigned char* am, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "maxpool_fwd")) return 1;
+  return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, dtype, S(stream));
+}
+int r3m_maxpool_bwd_dt(const void* dp, const unsigned char* am, void* dz, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "maxpool_bwd")) return 1;
+  return launch_maxpool_bwd(dp, am, dz, N, Hi, Wi, C, dtype, S(stream));
+}
+int r3m_avgpool_fwd_dt(const void* x, float* h, int N, int HW, int C, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "avgpool_fwd")) return 1;
+  return launch_avgpool_fwd(x, h, N, HW, C, dtype, S(stream));
+}
+int r3m_avgpool_bwd_dt(const float* dh, void* dx, int N, int HW, int C, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "avgpool_bwd")) return 1;
+  return launch_avgpool_bwd(dh, dx, N, HW, C, dtype, S(stream));
 }
 int r3m_maxpool_fwd(const float* z, float* p, unsigned char* am, int N, int Hi, int Wi, int C, r3m_stream_t stream) {
-  return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, S(stream));
+  return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, DT_F32, S(stream));
 }
 int r3m_maxpool_bwd(const float* dp, const unsigned char* am, float* dz, int N, int Hi, int Wi, int C, r3m_stream_t stream) {
-  return launch_maxpool_bwd(dp, am, dz, N, Hi, Wi, C, S(stream));
+  return launch_maxpool_bwd(dp, am, dz, N, Hi, Wi, C, DT_F32, S(stream));
 }
-int r3m_avgpool_fwd(const float* x, float* h, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_fwd(x, h, N, HW, C, S(stream)); }
-int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_bwd(dh, dx, N, HW, C, S(stream)); }
+int r3m_avgpool_fwd(const float* x, float* h, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_fwd(x, h, N, HW, C, DT_F32, S(stream)); }
+int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream_t stream) { return launch_avgpool_bwd(dh, dx, N, HW, C, DT_F32, S(stream)); }
 
 int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, int relu, r3m_stream_t stream) {
-  return conv_forward_launch(x, w, y, nullptr, bias, M, 1, 1, K, N, 1, 1, 0, (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0), S(stream));
+  return conv_forward_launch(x, w, y, nullptr, bias, M, 1, 1, K, N, 1, 1, 0, (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0), DT_F32, S(stream));
 }
 
 long long r3m_langrew_num_params(int D, int hidden, int lang_dim) { return langrew_num_params(D, hidden, lang_dim); }

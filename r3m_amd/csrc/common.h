@@ -36,6 +36,9 @@ enum : int {
 
 constexpr int MAX_TAPS = 49;
 
+// activation storage type of a launch / an encoder plan
+enum : int { DT_F32 = 0, DT_BF16 = 1 };
+
 // One launch of the gather-GEMM:  out[row(m), :] = sum_t  in[pix(m) + (dy_t, dx_t), :] * B[:, wt_t, :]^T
 struct GatherGemmParams {
   const float* A;      // input activations, NHWC [N, Hi, Wi, Ci]
@@ -57,6 +60,7 @@ struct GatherGemmParams {
   int flags;
   int simple_rows;     // 1: 1x1 / stride 1 / no padding -> input row offset = m*Ci (no pixel decode)
   int debug;           // timing probes (R3M_GG_DEBUG), 0 in production
+  int dtype;           // DT_F32: A/B/out/add0/add1 are fp32; DT_BF16: they address bf16 tensors (stats/bias stay fp32)
   signed char dy[MAX_TAPS];
   signed char dx[MAX_TAPS];
   unsigned char wt[MAX_TAPS];
@@ -75,6 +79,7 @@ struct WgradParams {
   int simple_rows;     // 1x1 stride-1: X row offset = m*Ci
   int tilesN;          // ceil(Ci / BN)
   int interleave;      // 1: spread the next K step's DMA pieces between this step's MFMAs (set by the launcher)
+  int dtype;           // DT_F32 / DT_BF16 storage of dY and X (out is always fp32)
 };
 
 // ---- launchers (conv.hip) ----
@@ -86,11 +91,18 @@ int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s);
 int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s);
-int launch_stem_fwd(const float* xn, const float* w147, float* y, float* stats, int F, hipStream_t s);
+int launch_stem_fwd(const float* xn, const float* w147, void* y, float* stats, int F, int dt, hipStream_t s);
 size_t stem_wgrad_ws_floats();
-int launch_stem_wgrad(const float* xn, const float* dY, float* dw147, float* ws, int F, int accumulate, hipStream_t s);
+int launch_stem_wgrad(const float* xn, const void* dY, float* dw147, float* ws, int F, int accumulate, int dt, hipStream_t s);
 int launch_pack_stem_w(const float* w147, float* w160, hipStream_t s);
 int launch_unpack_stem_dw(const float* dw160, float* dw147, int accumulate, hipStream_t s);
+
+// ---- launchers (conv_bf16.hip) ----
+int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s);
+int launch_wgrad_bf16(const WgradParams& p, int splitK, hipStream_t s);
+int wgrad_bf16_pick_split(int M, int Co, int Ci, int T);
+int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s);
+int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s);
 
 // ---- launchers (bn.hip) ----
 int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /*[<=64][2][C]*/, hipStream_t s);
@@ -99,21 +111,22 @@ int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, c
                             float* invstd, float* scale, float* shift, int C, hipStream_t s);
 int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                           float eps, float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s);
-int launch_bn_act_fwd(const float* Y, const float* scale, const float* shift, const float* R, const float* scale2,
-                      const float* shift2, float* Z, long long rows, int C, int relu, unsigned* maskbits, hipStream_t s);
+// activation tensors are void*: fp32 (dt = DT_F32) or bf16 (DT_BF16); coefficients / partials / statistics are fp32
+int launch_bn_act_fwd(const void* Y, const float* scale, const float* shift, const void* R, const float* scale2,
+                      const float* shift2, void* Z, long long rows, int C, int relu, unsigned* maskbits, int dt, hipStream_t s);
 int bn_bwd_partial_rows(long long rows, int C);
-int launch_bn_bwd_reduce(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
+int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
-                         hipStream_t s);
+                         int dt, hipStream_t s);
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
                                 float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s);
-int launch_bn_bwd_apply(const float* dZ, const float* Zmask, const unsigned* Zbits, const float* Y, const float* scale,
-                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, float* dY,
-                        long long rows, int C, hipStream_t s);
-int launch_maxpool_fwd(const float* Z, float* P, unsigned char* amax, int N, int Hi, int Wi, int C, hipStream_t s);
-int launch_maxpool_bwd(const float* dP, const unsigned char* amax, float* dZ, int N, int Hi, int Wi, int C, hipStream_t s);
-int launch_avgpool_fwd(const float* X, float* H, int N, int HW, int C, hipStream_t s);
-int launch_avgpool_bwd(const float* dH, float* dX, int N, int HW, int C, hipStream_t s);
+int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dY,
+                        long long rows, int C, int dt, hipStream_t s);
+int launch_maxpool_fwd(const void* Z, void* P, unsigned char* amax, int N, int Hi, int Wi, int C, int dt, hipStream_t s);
+int launch_maxpool_bwd(const void* dP, const unsigned char* amax, void* dZ, int N, int Hi, int Wi, int C, int dt, hipStream_t s);
+int launch_avgpool_fwd(const void* X, float* H, int N, int HW, int C, int dt, hipStream_t s);
+int launch_avgpool_bwd(const float* dH, void* dX, int N, int HW, int C, int dt, hipStream_t s);
 
 // ---- optional per-kernel-class HIP-event timing (bench.py roofline; off by default, zero cost when off) ----
 enum { KC_GEMM_WIDE = 0, KC_GEMM_NARROW = 1, KC_WGRAD_WIDE = 2, KC_WGRAD_NARROW = 3, KC_COUNT = 4 };

@@ -19,186 +19,15 @@
 // zero line / a clamped pixel) instead of being skipped, so the loader is straight-line code the compiler can interleave
 // with the MFMA stream; the tap table is a dword array in the kernarg segment (scalar loads).
 #include "common.h"
+#include "conv_dev.h"
 #include <cstdlib>
 #include <cstring>
 #include <utility>
 
 namespace r3m {
 
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — indices usable as array subscripts without scratch
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// zeros: the source of every out-of-image / out-of-range staging load of the direct-to-LDS kernels. Sized so that a
-// lane can keep walking its channel chunks (up to Ci = 2048 floats) along it like along a real pixel row.
 __device__ __attribute__((aligned(128))) float g_zero_line[2048 + 64];
 
-// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only). Remap so that
-// each XCD walks a contiguous range of logical tiles: tiles that share an operand panel then share one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int NX = 8;
-  const int xcd = bid % NX, idx = bid / NX;
-  const int q = nwg / NX, r = nwg % NX;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-// ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
-// Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
-// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
-// compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
-template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS>
-__device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                            int m0, int n0, int mt) {
-  constexpr int TM = BM / WM / 32;
-  constexpr int TN = BN / WN / 32;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int lrow = lane & 31;
-
-  if (EPI & EPI_STATS) {
-    // rows >= M were staged as zeros -> their accumulators are exactly 0 and add nothing to either sum
-    float* red = smem;  // [WM][2][BN]; the K loop ended with a barrier, the tiles are dead
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[tm][tn][r];
-          s += v;
-          ss = fmaf(v, v, ss);
-        }
-      s += __shfl_xor(s, 32);
-      ss += __shfl_xor(ss, 32);
-      if (lane < 32) {
-        const int c = (wn * TN + tn) * 32 + lane;
-        red[(wm * 2 + 0) * BN + c] = s;
-        red[(wm * 2 + 1) * BN + c] = ss;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s += red[(w * 2 + 0) * BN + tid];
-        ss += red[(w * 2 + 1) * BN + tid];
-      }
-      const int col = n0 + tid;
-      if (col < p.Nc) {
-        p.stats[((long long)mt * 2 + 0) * p.Nc + col] = s;
-        p.stats[((long long)mt * 2 + 1) * p.Nc + col] = ss;
-      }
-    }
-    __syncthreads();
-  }
-
-  constexpr int CW = TN * 32;          // columns owned by the wave
-  constexpr int CS = CW + 4;           // padded slab row stride (floats)
-  constexpr int F4 = CW / 4;           // float4 per slab row
-  constexpr int RPI = 64 / F4;         // rows covered per store instruction
-  static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
-  float* slab = smem + wave * 32 * CS;
-  const bool out_simple = (p.os == 1);
-  const int hwg = p.Hg * p.Wg;
-  const int ecol = (lane % F4) * 4;
-  const int erow = lane / F4;
-  const int gcol = n0 + wn * CW + ecol;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if ((EPI & EPI_BIAS) && gcol < p.Nc) bias4 = ldg4(p.bias + gcol);
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int lr = it * RPI + erow;
-      const int row = m0 + (wm * TM + tm) * 32 + lr;
-      if (row < p.M && gcol < p.Nc) {
-        long long roff;
-        if (out_simple) {
-          roff = (long long)row * p.Nc;
-        } else {
-          const int n = row / hwg;
-          const int rem = row - n * hwg;
-          const int gy = rem / p.Wg;
-          const int gx = rem - gy * p.Wg;
-          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
-        }
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
-        float* dst = p.out + roff + gcol;
-        if (EPI & EPI_BIAS) v += bias4;
-        if (EPI & EPI_ACCUM) v += ldg4(dst);
-        if (EPI & EPI_MASKED_ADD) {
-          const f32x4 g = ldg4(p.add0 + roff + gcol);
-          if (p.addbits) {
-            const long long i4 = (roff + gcol) >> 2;
-            const unsigned nb = (p.addbits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? g[e] : 0.f;
-          } else {
-            const f32x4 z = ldg4(p.add1 + roff + gcol);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (z[e] > 0.f) ? g[e] : 0.f;
-          }
-        }
-        if (EPI & EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (EPI & EPI_MASK_OUT) {
-          const f32x4 z = ldg4(p.add1 + roff + gcol);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(dst) = v;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// per-thread descriptor of one staged A row: image base offset + top-left input pixel of the GEMM row
-struct RowDesc {
-  long long base;
-  int iy, ix;
-};
-
-__device__ __forceinline__ RowDesc decode_row(const GatherGemmParams& p, int m) {
-  RowDesc d;
-  d.base = 0; d.iy = 0; d.ix = 0;
-  if (m < p.M) {
-    if (p.simple_rows) {
-      d.base = (long long)m * p.Ci;
-    } else {
-      const int hw = p.Hg * p.Wg;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      const int gy = rem / p.Wg;
-      const int gx = rem - gy * p.Wg;
-      d.base = (long long)n * p.Hi * p.Wi * p.Ci;
-      d.iy = gy * p.is;
-      d.ix = gx * p.is;
-    }
-  }
-  return d;
-}
 
 // =====================================================================================================
 // gather-GEMM, direct-to-LDS staging (the 128x128 work-horse).
@@ -728,6 +557,13 @@ static int gg_use_glds() {
 
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
+  if (p.dtype == DT_BF16) {
+    R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
+    R3M_REQUIRE(p.M > 0 && p.Nc > 0, "gather_gemm: empty problem M=%d Nc=%d", p.M, p.Nc);
+    for (int t = 0; t < p.ntaps; ++t)
+      p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
+    return launch_gather_gemm_bf16(p, s);
+  }
   R3M_REQUIRE(p.Ci % 32 == 0, "gather_gemm: Ci=%d must be a multiple of 32", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm: Nc=%d must be a multiple of 4", p.Nc);
   R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
@@ -1210,7 +1046,7 @@ __device__ __forceinline__ void stem_load_patch(const float* __restrict__ xn, fl
   }
 }
 
-template <int EPI>
+template <int EPI, class OT>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w,
                                                         const GatherGemmParams p, int ntiles) {
   constexpr int SMEM = 13 * ST_PS + 64 * ST_KS;
@@ -1265,22 +1101,27 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     __syncthreads();
-    gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS>(p, acc, smem, blk * 256, 0, blk);   // ends with a barrier
+    gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS, OT>(p, acc, smem, blk * 256, 0, blk);   // ends with a barrier
   }
 }
 
-int launch_stem_fwd(const float* x_nchw, const float* w147, float* y, float* stats, int F, hipStream_t s) {
+int launch_stem_fwd(const float* x_nchw, const float* w147, void* y, float* stats, int F, int dt, hipStream_t s) {
   GatherGemmParams p;
   memset(&p, 0, sizeof p);
-  p.out = y; p.stats = stats;
+  p.out = static_cast<float*>(y); p.stats = stats; p.dtype = dt;
   p.M = F * 12544; p.Nc = 64; p.os = 1;
   p.Hg = 112; p.Wg = 112; p.Ho = 112; p.Wo = 112;
   const double flops = 2.0 * (double)p.M * 64.0 * 147.0;
   prof_begin(KC_GEMM_NARROW, flops, p.M, 64, 147, 1, s);
   const int ntiles = F * 49;
   const int grid = ntiles < 512 ? ntiles : 512;   // persistent blocks (2 per CU): the 39 KB weight image is staged once per block
-  if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
-  else hipLaunchKernelGGL((stem_fwd_kernel<0>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+  if (dt == DT_BF16) {
+    if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS, bf16_t>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+    else hipLaunchKernelGGL((stem_fwd_kernel<0, bf16_t>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+  } else {
+    if (stats) hipLaunchKernelGGL((stem_fwd_kernel<EPI_STATS, float>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+    else hipLaunchKernelGGL((stem_fwd_kernel<0, float>), dim3(grid), dim3(256), 0, s, x_nchw, w147, p, ntiles);
+  }
   prof_end(s);
   return check_launch("stem_fwd");
 }
@@ -1288,7 +1129,8 @@ int launch_stem_fwd(const float* x_nchw, const float* w147, float* y, float* sta
 // dW[co][kh*22 + j] partial of one block = sum over its output image rows of dY[m][co] * patch(m, kh, j).
 // One output image row (112 pixels = 56 K pairs) per iteration: 7 input rows + the dY row in LDS, per-lane bases plus
 // immediates (pixel step = 6 floats of the interleaved row). Waves: 2 (co halves) x 2 (k tiles {0,1,2} / {3,4}).
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dY,
+template <class T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dY,
                                                           float* __restrict__ partial, int total_rows) {
   __shared__ __attribute__((aligned(16))) float smem[7 * ST_PS + 112 * 64];
   float* patch = smem;
@@ -1321,8 +1163,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const long long f = row / 112;
     const int oy = row - (int)f * 112;
     stem_load_patch(x, patch, f, 2 * oy - 3, 7);
-    const float* src = dY + (long long)row * 112 * 64;
-    for (int i = tid; i < 112 * 16; i += 256) *reinterpret_cast<f32x4*>(dys + i * 4) = ldg4(src + i * 4);
+    const T* src = dY + (long long)row * 112 * 64;
+    for (int i = tid; i < 112 * 16; i += 256) *reinterpret_cast<f32x4*>(dys + i * 4) = ld4t(src + i * 4);
     __syncthreads();
     if (wj == 0) {
 #pragma unroll
@@ -1370,13 +1212,16 @@ __global__ void stem_unpack_dw22_kernel(const float* __restrict__ dw160, float* 
   dw147[i] = accumulate ? dw147[i] + v : v;
 }
 
-int launch_stem_wgrad(const float* x_nchw, const float* dY, float* dw147, float* ws /* stem_wgrad_ws_floats() + 64*160 */, int F,
-                      int accumulate, hipStream_t s) {
+int launch_stem_wgrad(const float* x_nchw, const void* dY, float* dw147, float* ws /* stem_wgrad_ws_floats() + 64*160 */, int F,
+                      int accumulate, int dt, hipStream_t s) {
   const int total_rows = F * 112;
   const int nb = total_rows < STEM_WG_BLOCKS ? total_rows : STEM_WG_BLOCKS;
   const double flops = 2.0 * (double)F * 12544.0 * 64.0 * 147.0;
   prof_begin(KC_WGRAD_NARROW, flops, F * 12544, 64, 147, 1, s);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, s, x_nchw, dY, ws, total_rows);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, x_nchw, static_cast<const bf16_t*>(dY), ws, total_rows);
+  else
+    hipLaunchKernelGGL((stem_wgrad_kernel<float>), dim3(nb), dim3(256), 0, s, x_nchw, static_cast<const float*>(dY), ws, total_rows);
   prof_end(s);
   if (int e = check_launch("stem_wgrad")) return e;
   float* dw160 = ws + stem_wgrad_ws_floats();

@@ -1,0 +1,458 @@
+// r3m_amd — bf16-activation convolution path for gfx950 (BASELINE configs[2], [4]: "bf16"): the same implicit GEMMs as
+// conv.hip with bf16 operands in HBM/LDS, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 BatchNorm partials taken
+// from the accumulators, fp32 weight gradients. Master weights, optimizer state and every per-channel statistic stay
+// fp32 (r3m_amd/encoder.py precision="bf16" is the mixed-precision counterpart of torch.autocast around the reference's
+// encoder call, /root/reference/r3m/models/models_r3m.py:99; the reference itself trains in fp32).
+//
+//   gather_gemm_bf16_kernel : forward / dgrad. LDS rows are 64 bf16 = 128 B, the very byte image of the fp32 kernel
+//       (8 rows per global_load_lds instruction, 16-byte slots XOR-swizzled by (row>>1)&7), so the fragment of MFMA step g
+//       is ONE ds_read_b128 = 8 consecutive k of one row — exactly the 32x32x16 operand layout (k = 8*(lane>>5)..+7).
+//   wgrad_bf16_kernel : the contraction runs over rows m while both operands are channel-contiguous, i.e. K-strided in
+//       LDS. gfx950's transpose read (ds_read_b64_tr_b16) turns a [4 k][16 channel] LDS block into 4 consecutive k per
+//       lane, so the operands still arrive by plain row DMA and no packing VALU is spent. 64-byte channel groups are
+//       XOR-swizzled by the k row so the 4 rows one read touches sit in 4 different bank quarters.
+#include "common.h"
+#include "conv_dev.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace r3m {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_bytes[512];
+
+__device__ __forceinline__ const char* sel_ptr(const char* s, const char* z, bool ok) {
+  // bitwise select keeps the loader straight-line (a ?: is turned back into an exec-masked branch)
+  const unsigned long long msk = ok ? ~0ull : 0ull;
+  return reinterpret_cast<const char*>((reinterpret_cast<unsigned long long>(s) & msk) |
+                                       (reinterpret_cast<unsigned long long>(z) & ~msk));
+}
+
+__device__ __forceinline__ void dma16(const char* src, unsigned char* lds) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// =====================================================================================================
+// gather-GEMM on bf16 operands. Block BM x BN, K step 64 (one 128-byte row per GEMM row), 4 waves as WM x WN, each wave
+// 2 x 2 MFMA tiles. Two LDS stages; tile t+1's DMA is issued right after the barrier that publishes tile t, its pieces
+// spread between tile t's MFMAs.
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmParams p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM == 2 && TN == 2, "wave tile is 64 x 64");
+  constexpr int AJ = BM / 32, BJ = BN / 32;             // DMA instructions per wave per tile (8 rows each)
+  constexpr int NP = AJ + BJ;
+  constexpr int STAGE = (BM + BN) * 128;                 // bytes
+  __shared__ __attribute__((aligned(128))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Bb = reinterpret_cast<const char*>(p.B);
+
+  const int srow = lane >> 3, pslot = lane & 7;
+  const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  RowDesc ad[AJ];
+  int acol[AJ];                        // byte offset inside the 128-byte K chunk this lane fetches (swizzled)
+  unsigned arow_ok = 0;
+  const char* bptr[BJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int r = wave * (BM / 4) + j * 8 + srow;
+    acol[j] = (pslot ^ ((r >> 1) & 7)) * 16;
+    const int m = m0 + r;
+    ad[j] = decode_row(p, m);
+    if (m < p.M) arow_ok |= 1u << j;
+  }
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int r = wave * (BN / 4) + j * 8 + srow;
+    const int n = min(n0 + r, p.Nc - 1);                  // columns past Nc are computed on a clamped row, never stored
+    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ ((r >> 1) & 7)) * 16;
+  }
+  const char* zline = reinterpret_cast<const char*>(g_zero_bytes) + pslot * 16;
+
+  const int kpt = p.Ci >> 6;          // K tiles per tap
+  const int nk = p.ntaps * kpt;
+
+  // one DMA piece of the tile (pack = tap descriptor, c0b = byte offset of the channel chunk)
+  auto issue_piece = [&](int pack, int c0b, int stage, auto pc_c) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pc_c)::value;
+    unsigned char* la = smem + stage * STAGE + wave * (BM / 4) * 128;
+    unsigned char* lb = smem + stage * STAGE + BM * 128 + wave * (BN / 4) * 128;
+    if constexpr (pc < AJ) {
+      constexpr int j = pc;
+      const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24;
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
+      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
+      const char* src = Ab + (ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci) * 2 + c0b + acol[j];
+      dma16(sel_ptr(src, zline, in), la + j * 8 * 128);
+    } else {
+      constexpr int j = pc - AJ;
+      const int wt = pack >> 16;
+      dma16(bptr[j] + (long long)wt * p.Ci * 2 + c0b, lb + j * 8 * 128);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment addressing: row = lrow (+32 per MFMA tile), logical slot 2g+h, physical slot = logical ^ ((row>>1)&7)
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int xr = (lrow >> 1) & 7;
+  int goff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) goff[g] = ((2 * g + lh) ^ xr) * 16;
+  const unsigned char* fragA0 = smem + (wm * 64 + lrow) * 128;
+  const unsigned char* fragB0 = smem + BM * 128 + (wn * 64 + lrow) * 128;
+
+  int tap_n = 0, chunk_n = 0;
+  int pack_cur = nk > 0 ? p.tap[0] : 0;
+  int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
+  if (nk > 0) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(pack_cur, 0, 0, pc); });
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of tile kt has landed
+    __syncthreads();                                   // everyone's has; and everyone is done reading stage cur^1
+    const bool more = kt + 1 < nk;
+    if (more) {
+      if (++chunk_n == kpt) {
+        chunk_n = 0;
+        ++tap_n;
+        pack_cur = pack_next;
+        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      }
+    }
+    const int c0b = chunk_n * 128;
+    const unsigned char* fa = fragA0 + cur * STAGE;
+    const unsigned char* fb = fragB0 + cur * STAGE;
+    static_for<4>([&](auto g_c) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_c)::value;
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * 128 + goff[g]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * 128 + goff[g]);
+      // the next tile's DMA pieces, NP/4 per MFMA group
+      if (more) {
+        constexpr int P0 = g * NP / 4, P1 = (g + 1) * NP / 4;     // NP = 8 or 10: 2,2,2,2 / 2,3,2,3 pieces per group
+        static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
+          issue_piece(pack_cur, c0b, cur ^ 1, std::integral_constant<int, P0 + decltype(q_c)::value>{});
+        });
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    });
+  }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the stages
+
+  gg_epilogue<BM, BN, WM, WN, EPI, 2 * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
+}
+
+static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
+
+int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
+  R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
+  R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);
+  const double flops = 2.0 * (double)p.M * (double)p.Nc * (double)p.ntaps * p.Ci;
+#define GG16_SWITCH(BM, BN, WM, WN)                                                                                   \
+  switch (p.flags) {                                                                                                   \
+    case 0: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), 0, s, p); break;   \
+    case EPI_STATS: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_STATS>), dim3(grid), dim3(256), 0, s, p); break; \
+    case EPI_ACCUM: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_ACCUM>), dim3(grid), dim3(256), 0, s, p); break; \
+    case EPI_MASKED_ADD: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_MASKED_ADD>), dim3(grid), dim3(256), 0, s, p); break; \
+    default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;         \
+  }
+  if (gg_wide(p.Nc)) {
+    const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
+    prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    GG16_SWITCH(128, 128, 2, 2)
+  } else {
+    const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
+    prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    GG16_SWITCH(256, 64, 4, 1)
+  }
+#undef GG16_SWITCH
+  prof_end(s);
+  return check_launch("gather_gemm_bf16");
+}
+
+// =====================================================================================================
+// wgrad on bf16 operands: dW[co, tap, ci] (fp32 split-K partials) = sum_m dY[m, co] * X[pix(m) + off(tap), ci].
+// Block tile BMt (co) x BNt (ci), K step 64 rows, 4 waves as 2 x 2. LDS image per operand: [64 k][BMt] bf16, a k row is
+// BMt*2 bytes, one DMA instruction covers 1 KiB = 4 (128 wide) or 8 (64 wide) k rows. 64-byte channel groups are
+// XOR-swizzled with the k row (on the DMA's global source side and again on the fragment read).
+// Fragment of MFMA step s, half r: ds_read_b64_tr_b16 — in each 16-lane group lane c returns element (c & 3) of what
+// lane 4j + (c >> 2) addressed, for j = 0..3. With lane q = 4j + i addressing k row kb + j, channels cb + 4i..4i+3, lane c
+// receives channel cb + c at k = kb..kb+3: four consecutive k of one channel — half an MFMA operand.
+// =====================================================================================================
+template <int BMt, int BNt>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
+  constexpr int BK = 64;
+  constexpr int TM = BMt / 64, TN = BNt / 64;
+  constexpr int A_ROWB = BMt * 2, B_ROWB = BNt * 2;            // bytes per k row
+  constexpr int A_RPI = 1024 / A_ROWB, B_RPI = 1024 / B_ROWB;  // k rows per DMA instruction
+  constexpr int AJ = 16 / A_RPI, BJ = 16 / B_RPI;              // instructions per wave per stage (16 k rows per wave)
+  constexpr int NP = AJ + BJ;
+  constexpr int STAGE = BK * (A_ROWB + B_ROWB);
+  __shared__ __attribute__((aligned(256))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = p.KH * p.KW;
+  const int tap = blockIdx.x % T;
+  const int tile = blockIdx.x / T;
+  const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
+  const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int ms = blockIdx.y * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  const int hw = p.Ho * p.Wo;
+  const char* dYb = reinterpret_cast<const char*>(p.dY);
+  const char* Xb = reinterpret_cast<const char*>(p.X);
+
+  // swizzle key of a k row: 4 consecutive rows must land in 4 different 64-byte bank quarters
+  //   128 wide (256-byte rows): key = row & 3;   64 wide (128-byte rows, two per bank line): key = (row >> 1) & 1
+  // DMA lane -> (k row within the instruction, physical 16-byte slot) -> logical slot = physical ^ 4*key
+  const int a_k = lane / (A_ROWB / 16), a_ps = lane % (A_ROWB / 16);
+  const int b_k = lane / (B_ROWB / 16), b_ps = lane % (B_ROWB / 16);
+  const int a_key = (BMt == 128) ? (a_k & 3) : ((a_k >> 1) & 1);
+  const int b_key = (BNt == 128) ? (b_k & 3) : ((b_k >> 1) & 1);
+  const int a_cb = (co0 + (a_ps ^ (4 * a_key)) * 8) * 2;       // byte offset of this lane's 8 channels inside a dY row
+  const int b_cb = (ci0 + (b_ps ^ (4 * b_key)) * 8) * 2;
+  const char* zl = reinterpret_cast<const char*>(g_zero_bytes) + (lane & 15) * 16;
+
+  int a_m[AJ];
+  const char* a_ptr[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    a_m[j] = ms + wave * 16 + j * A_RPI + a_k;
+    a_ptr[j] = dYb + (long long)a_m[j] * p.Co * 2 + a_cb;
+  }
+  const int q64 = 64 / p.Wo, r64 = 64 - q64 * p.Wo;
+  const bool fast_adv = (q64 + 1) <= p.Ho;
+  const long long img = (long long)p.Hi * p.Wi * p.Ci * 2;
+  int b_m[BJ];
+  const char* b_ptr[BJ];   // simple rows: running pointer; otherwise image base pointer of the row's frame
+  int xoy[BJ], xox[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    b_m[j] = ms + wave * 16 + j * B_RPI + b_k;
+    xoy[j] = 0; xox[j] = 0;
+    if (p.simple_rows) {
+      b_ptr[j] = Xb + (long long)b_m[j] * p.Ci * 2 + b_cb;
+    } else {
+      const int n = b_m[j] / hw;
+      const int rem = b_m[j] - n * hw;
+      xoy[j] = rem / p.Wo;
+      xox[j] = rem - xoy[j] * p.Wo;
+      b_ptr[j] = Xb + (long long)n * img + b_cb;
+    }
+  }
+  const long long a_step = 64LL * p.Co * 2, b_step = 64LL * p.Ci * 2;
+
+  auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pc_c)::value;
+    if constexpr (pc < AJ) {
+      constexpr int j = pc;
+      unsigned char* la = smem + stage * STAGE + (wave * 16 + j * A_RPI) * A_ROWB;
+      dma16(sel_ptr(a_ptr[j], zl, a_m[j] < me), la);
+      a_m[j] += 64;
+      a_ptr[j] += a_step;
+    } else {
+      constexpr int j = pc - AJ;
+      unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * 16 + j * B_RPI) * B_ROWB;
+      const char* src;
+      if (p.simple_rows) {
+        src = sel_ptr(b_ptr[j], zl, b_m[j] < me);
+        b_ptr[j] += b_step;
+      } else {
+        const int iy = xoy[j] * p.stride + kh - p.pad, ix = xox[j] * p.stride + kw - p.pad;
+        const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (b_m[j] < me);
+        src = sel_ptr(b_ptr[j] + ((long long)iy * p.Wi + ix) * p.Ci * 2, zl, in);   // never dereferenced when out of the image
+        if (fast_adv) {
+          int ox = xox[j] + r64, oy = xoy[j] + q64;
+          const bool cx = ox >= p.Wo;
+          ox = cx ? ox - p.Wo : ox;
+          oy = cx ? oy + 1 : oy;
+          const bool cy = oy >= p.Ho;
+          oy = cy ? oy - p.Ho : oy;
+          b_ptr[j] = cy ? b_ptr[j] + img : b_ptr[j];
+          xox[j] = ox; xoy[j] = oy;
+        } else {
+          const int m = b_m[j] + 64;
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          xoy[j] = rem / p.Wo;
+          xox[j] = rem - xoy[j] * p.Wo;
+          b_ptr[j] = Xb + (long long)n * img + b_cb;
+        }
+      }
+      dma16(src, lb);
+      b_m[j] += 64;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transpose-read addressing. Lane l: group-local q = l & 15 addresses k row 8*(l>>5) + (q>>2) (+16s + 4r as an immediate),
+  // channels [16*((l>>4)&1) + 4*(q&3), +4) of its MFMA tile; the tile's 64-byte group index is XORed with the row key.
+  const int q = lane & 15;
+  const int frow = 8 * (lane >> 5) + (q >> 2);
+  const int fkeyA = (BMt == 128) ? (frow & 3) : ((frow >> 1) & 1);
+  const int fkeyB = (BNt == 128) ? (frow & 3) : ((frow >> 1) & 1);
+  const int fcol = (16 * ((lane >> 4) & 1) + 4 * (q & 3)) * 2;       // byte offset inside the tile's 64-byte group
+  int fa_off[TM], fb_off[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) fa_off[t] = frow * A_ROWB + (((wm * TM + t) ^ fkeyA) * 64) + fcol;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) fb_off[t] = BK * A_ROWB + frow * B_ROWB + (((wn * TN + t) ^ fkeyB) * 64) + fcol;
+
+  auto tr_read = [&](const unsigned char* ptr) __attribute__((always_inline)) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  };
+  auto frag = [&](const unsigned char* base, int rowb, int sidx) __attribute__((always_inline)) {
+    const s16x4 lo = tr_read(base + (16 * sidx) * rowb);
+    const s16x4 hi = tr_read(base + (16 * sidx + 4) * rowb);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  auto mfma_stage = [&](const unsigned char* st, int dma_stage) __attribute__((always_inline)) {
+    static_for<4>([&](auto s_c) __attribute__((always_inline)) {
+      constexpr int sidx = decltype(s_c)::value;
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) a[t] = frag(st + fa_off[t], A_ROWB, sidx);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) b[t] = frag(st + fb_off[t], B_ROWB, sidx);
+      if (dma_stage >= 0) {
+        constexpr int P0 = sidx * NP / 4, P1 = (sidx + 1) * NP / 4;
+        static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
+          issue_piece(dma_stage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
+        });
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    });
+  };
+
+  const int nk = (me - ms + BK - 1) / BK;
+  if (nk > 0) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(0, pc); });
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    mfma_stage(smem + cur * STAGE, (kt + 1 < nk) ? (cur ^ 1) : -1);
+  }
+
+  float* out = p.out + (long long)blockIdx.y * p.Co * T * p.Ci;
+  const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
+        out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
+      }
+    }
+}
+
+static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
+
+// split-K factor: enough blocks to fill the chip ~4 (wide) / ~10 (narrow) times, rows per split a multiple of 64
+int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
+  const bool wide = wg_wide(Co, Ci);
+  const int tiles = wide ? (Co / 128) * (Ci / 128) * T : ceil_div(Co, 64) * ceil_div(Ci, 64) * T;
+  int split = (wide ? 1024 : 2560) / (tiles > 0 ? tiles : 1);
+  const int max_split = ceil_div(M, 256);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  return split;
+}
+
+int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
+  WgradParams p = p0;
+  R3M_REQUIRE(p.Co % 64 == 0 && p.Ci % 64 == 0, "wgrad(bf16): Co=%d, Ci=%d must be multiples of 64", p.Co, p.Ci);
+  const int T = p.KH * p.KW;
+  const bool wide = wg_wide(p.Co, p.Ci);
+  p.rows_per_split = ceil_div(ceil_div(p.M, splitK), 64) * 64;
+  p.tilesN = wide ? p.Ci / 128 : p.Ci / 64;
+  const int tilesM = wide ? p.Co / 128 : p.Co / 64;
+  const double flops = 2.0 * (double)p.M * p.Co * (double)p.Ci * T;
+  prof_begin(wide ? KC_WGRAD_WIDE : KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
+  const dim3 grid(tilesM * p.tilesN * T, splitK);
+  if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+  prof_end(s);
+  return check_launch("wgrad_bf16");
+}
+
+// ---- weight images: fp32 master [Co][T][Ci] -> bf16 copy (forward) / bf16 [Ci][T][Co] (dgrad) ----
+__global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) st4t(dst + i * 4, ld4t(src + i * 4));
+}
+
+int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s) {
+  R3M_REQUIRE(n % 4 == 0, "convert_bf16: n=%lld must be a multiple of 4", n);
+  hipLaunchKernelGGL(convert_bf16_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, s, src, reinterpret_cast<bf16_t*>(dst), n / 4);
+  return check_launch("convert_bf16");
+}
+
+__global__ __launch_bounds__(256) void transpose_w_bf16_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wt, int Co, int T, int Ci) {
+  // Wt[ci][t][co] = W[co][t][ci]; a 32 x 32 (co, ci) tile per block through LDS, both sides coalesced
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Co && ci < Ci) ? W[((long long)co * T + t) * Ci + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Ci && co < Co) Wt[((long long)ci * T + t) * Co + co] = (bf16_t)tile[tx][r];
+  }
+}
+
+int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(ceil_div(Ci, 32), ceil_div(Co, 32), T), dim3(256), 0, s, W,
+                     reinterpret_cast<bf16_t*>(Wt), Co, T, Ci);
+  return check_launch("transpose_w_bf16");
+}
+
+}  // namespace r3m

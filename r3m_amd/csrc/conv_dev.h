@@ -1,0 +1,189 @@
+// r3m_amd — device helpers shared by the convolution translation units (conv.hip: fp32, conv_bf16.hip: bf16 activations).
+#pragma once
+#include "common.h"
+#include <utility>
+
+namespace r3m {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 4 consecutive activations as fp32, whatever the storage type (bf16 <-> fp32 conversions are exact / round-to-nearest-even)
+__device__ __forceinline__ f32x4 ld4t(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4t(const bf16_t* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4); }
+__device__ __forceinline__ void st4t(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4t(bf16_t* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — indices usable as array subscripts without scratch
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed; speed only). Remap so that
+// each XCD walks a contiguous range of logical tiles: tiles that share an operand panel then share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  const int xcd = bid % NX, idx = bid / NX;
+  const int q = nwg / NX, r = nwg % NX;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
+// Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
+// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
+// compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
+template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS, class OT = float>
+__device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                            int m0, int n0, int mt) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 31;
+
+  if (EPI & EPI_STATS) {
+    // rows >= M were staged as zeros -> their accumulators are exactly 0 and add nothing to either sum
+    float* red = smem;  // [WM][2][BN]; the K loop ended with a barrier, the tiles are dead
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r];
+          s += v;
+          ss = fmaf(v, v, ss);
+        }
+      s += __shfl_xor(s, 32);
+      ss += __shfl_xor(ss, 32);
+      if (lane < 32) {
+        const int c = (wn * TN + tn) * 32 + lane;
+        red[(wm * 2 + 0) * BN + c] = s;
+        red[(wm * 2 + 1) * BN + c] = ss;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(w * 2 + 0) * BN + tid];
+        ss += red[(w * 2 + 1) * BN + tid];
+      }
+      const int col = n0 + tid;
+      if (col < p.Nc) {
+        p.stats[((long long)mt * 2 + 0) * p.Nc + col] = s;
+        p.stats[((long long)mt * 2 + 1) * p.Nc + col] = ss;
+      }
+    }
+    __syncthreads();
+  }
+
+  constexpr int CW = TN * 32;          // columns owned by the wave
+  constexpr int CS = CW + 4;           // padded slab row stride (floats)
+  constexpr int F4 = CW / 4;           // float4 per slab row
+  constexpr int RPI = 64 / F4;         // rows covered per store instruction
+  static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
+  float* slab = smem + wave * 32 * CS;
+  const bool out_simple = (p.os == 1);
+  const int hwg = p.Hg * p.Wg;
+  const int ecol = (lane % F4) * 4;
+  const int erow = lane / F4;
+  const int gcol = n0 + wn * CW + ecol;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if ((EPI & EPI_BIAS) && gcol < p.Nc) bias4 = ldg4(p.bias + gcol);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int lr = it * RPI + erow;
+      const int row = m0 + (wm * TM + tm) * 32 + lr;
+      if (row < p.M && gcol < p.Nc) {
+        long long roff;
+        if (out_simple) {
+          roff = (long long)row * p.Nc;
+        } else {
+          const int n = row / hwg;
+          const int rem = row - n * hwg;
+          const int gy = rem / p.Wg;
+          const int gx = rem - gy * p.Wg;
+          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
+        OT* dst = reinterpret_cast<OT*>(p.out) + roff + gcol;     // activation pointers are typed float in the params struct;
+        if (EPI & EPI_BIAS) v += bias4;                           // with OT = bf16_t they address bf16 tensors
+        if (EPI & EPI_ACCUM) v += ld4t(dst);
+        if (EPI & EPI_MASKED_ADD) {
+          const f32x4 g = ld4t(reinterpret_cast<const OT*>(p.add0) + roff + gcol);
+          if (p.addbits) {
+            const long long i4 = (roff + gcol) >> 2;
+            const unsigned nb = (p.addbits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? g[e] : 0.f;
+          } else {
+            const f32x4 z = ld4t(reinterpret_cast<const OT*>(p.add1) + roff + gcol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (z[e] > 0.f) ? g[e] : 0.f;
+          }
+        }
+        if (EPI & EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (EPI & EPI_MASK_OUT) {
+          const f32x4 z = ld4t(reinterpret_cast<const OT*>(p.add1) + roff + gcol);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
+        }
+        st4t(dst, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// per-thread descriptor of one staged A row: image base offset + top-left input pixel of the GEMM row
+struct RowDesc {
+  long long base;
+  int iy, ix;
+};
+
+__device__ __forceinline__ RowDesc decode_row(const GatherGemmParams& p, int m) {
+  RowDesc d;
+  d.base = 0; d.iy = 0; d.ix = 0;
+  if (m < p.M) {
+    if (p.simple_rows) {
+      d.base = (long long)m * p.Ci;
+    } else {
+      const int hw = p.Hg * p.Wg;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int gy = rem / p.Wg;
+      const int gx = rem - gy * p.Wg;
+      d.base = (long long)n * p.Hi * p.Wi * p.Ci;
+      d.iy = gy * p.is;
+      d.ix = gx * p.is;
+    }
+  }
+  return d;
+}
+
+}  // namespace r3m

@@ -52,6 +52,8 @@ struct TensorInfo {
 
 struct Plan {
   int size, F, D;
+  int dtype = DT_F32;     // activation storage: fp32, or bf16 (bf16 conv operands, fp32 accumulation / statistics / gradients of weights)
+  long long w16_off = 0;  // arena: bf16 image of the flat parameter buffer (DT_BF16 only)
   std::vector<ConvSpec> convs;
   std::vector<BlockSpec> blocks;
   std::vector<TensorInfo> tensors;
@@ -103,12 +105,13 @@ static int add_conv(Plan& P, const std::string& name, const std::string& bn, int
   return (int)P.convs.size() - 1;
 }
 
-Plan* plan_create(int size, int F) {
+Plan* plan_create(int size, int F, int dtype) {
   if (size != 18 && size != 34 && size != 50) { set_last_error("resnet: unsupported size %d (18, 34, 50)", size); return nullptr; }
+  if (dtype != DT_F32 && dtype != DT_BF16) { set_last_error("resnet: unsupported dtype %d (0 fp32, 1 bf16)", dtype); return nullptr; }
   if (F < 1) { set_last_error("resnet: F=%d must be >= 1", F); return nullptr; }
   Plan* Pp = new Plan();
   Plan& P = *Pp;
-  P.size = size; P.F = F;
+  P.size = size; P.F = F; P.dtype = dtype;
   const bool bottleneck = (size == 50);
   const int expansion = bottleneck ? 4 : 1;
   const int nblk[4] = {size == 18 ? 2 : 3, size == 18 ? 2 : 4, size == 18 ? 2 : 6, size == 18 ? 2 : 3};
@@ -153,14 +156,16 @@ Plan* plan_create(int size, int F) {
   long long off = 0;
   auto take = [&](long long n) { long long o = off; off = align64(off + n); return o; };
   const long long Fll = F;
+  // arena offsets are in floats whatever the storage type; a bf16 tensor of n elements takes n/2 of them
+  auto act = [&](long long n) { return dtype == DT_BF16 ? (n + 1) / 2 : n; };
   P.col_off = take(Fll * 3 * 224 * 224);   // private copy of the input frames: the stem's weight gradient re-reads them in backward
   long long gmax = 0, partial_max = 0, wmax = 0, wgp_max = 0;
   auto act_elems = [&](const ConvSpec& c) { return Fll * c.Ho * c.Wo * c.Co; };
   for (size_t i = 0; i < P.convs.size(); ++i) {
     ConvSpec& c = P.convs[i];
-    c.Y_off = take(act_elems(c));
+    c.Y_off = take(act(act_elems(c)));
     c.coef_off = take(6LL * c.Co);
-    if (act_elems(c) > gmax) gmax = act_elems(c);
+    if (act(act_elems(c)) > gmax) gmax = act(act_elems(c));
     const int M = F * c.Ho * c.Wo;
     c.stats_rows = gather_gemm_grid_m(M, c.Co);
     long long pr = (long long)c.stats_rows * 2 * c.Co;
@@ -173,25 +178,26 @@ Plan* plan_create(int size, int F) {
       const long long need = (long long)stem_wgrad_ws_floats() + 64 * 160;
       if (need > wgp_max) wgp_max = need;
     } else {
-      const int split = wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
+      const int split = dtype == DT_BF16 ? wgrad_bf16_pick_split(M, c.Co, c.Ci, c.k * c.k) : wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
       if (welems * split > wgp_max) wgp_max = welems * split;
     }
   }
   // stem: Z0 (pre-pool activation), P0 (pooled), argmax bytes
-  P.convs[0].Z_off = take(act_elems(P.convs[0]));
-  P.P0_off = take(Fll * 56 * 56 * 64);
+  P.convs[0].Z_off = take(act(act_elems(P.convs[0])));
+  P.P0_off = take(act(Fll * 56 * 56 * 64));
   P.amax_off = take((Fll * 56 * 56 * 64 + 3) / 4);
   long long cur_in = P.P0_off;
   for (auto& B : P.blocks) {
     B.in_off = cur_in;
-    for (int j = 0; j < B.nconv - 1; ++j) P.convs[B.conv[j]].Z_off = take(act_elems(P.convs[B.conv[j]]));
-    B.out_off = take(Fll * B.Ho * B.Wo * B.Co);
+    for (int j = 0; j < B.nconv - 1; ++j) P.convs[B.conv[j]].Z_off = take(act(act_elems(P.convs[B.conv[j]])));
+    B.out_off = take(act(Fll * B.Ho * B.Wo * B.Co));
     B.mask_off = take((Fll * B.Ho * B.Wo * B.Co + 31) / 32);
     cur_in = B.out_off;
   }
   P.partial_off = take(partial_max);
   P.acc_off = take(64LL * 2 * 2048 * 2);  // doubles: 64 slices x 2 x Cmax, in float units x2
   P.wt_off = take(wmax);
+  if (dtype == DT_BF16) P.w16_off = take((P.n_params + 1) / 2);
   P.wgp_off = take(wgp_max);
   P.gmax = gmax;
   for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
@@ -209,6 +215,7 @@ struct Ctx {
   hipStream_t s;
   int training;
   int accumulate;
+  int dt;
 };
 
 static void fill_taps_fwd(GatherGemmParams& g, int k, int pad) {
@@ -220,10 +227,12 @@ static void fill_taps_fwd(GatherGemmParams& g, int k, int pad) {
   g.ntaps = t;
 }
 
+// X / W / Y (and dY / Wt / dX / add0 / add1, X / dY below) are fp32 tensors, or bf16 tensors behind float-typed pointers when dt == DT_BF16
 int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
-                        int Co, int k, int stride, int pad, int flags, hipStream_t s) {
+                        int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s) {
   GatherGemmParams g;
   memset(&g, 0, sizeof g);
+  g.dtype = dt;
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   g.A = X; g.B = W; g.out = Y; g.stats = stats; g.bias = bias;
   g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
@@ -239,11 +248,12 @@ int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, 
 
 // dX[N,Hi,Wi,Ci] = dgrad of conv(k, stride, pad) given dY[N,Ho,Wo,Co] and Wt[Ci][k*k][Co]
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
-                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s) {
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   R3M_REQUIRE(stride == 1 || stride == 2, "dgrad: stride %d", stride);
   GatherGemmParams g;
   memset(&g, 0, sizeof g);
+  g.dtype = dt;
   g.A = dY; g.B = Wt; g.out = dX; g.add0 = add0; g.add1 = add1; g.addbits = addbits;
   g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co;   // the GEMM "input" is dY
   g.Ho = Hi; g.Wo = Wi; g.Nc = Ci;
@@ -286,23 +296,29 @@ int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* 
 }
 
 int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
-                      int stride, int pad, int accumulate, hipStream_t s) {
+                      int stride, int pad, int accumulate, int dt, hipStream_t s) {
   WgradParams w;
   memset(&w, 0, sizeof w);
+  w.dtype = dt;
   w.Ho = (Hi + 2 * pad - k) / stride + 1; w.Wo = (Wi + 2 * pad - k) / stride + 1;
   w.dY = dY; w.X = X; w.out = partial_ws;
   w.N = N; w.Hi = Hi; w.Wi = Wi; w.Ci = Ci; w.Co = Co;
   w.KH = w.KW = k; w.stride = stride; w.pad = pad;
   w.M = N * w.Ho * w.Wo;
   w.simple_rows = (k == 1 && stride == 1 && pad == 0) ? 1 : 0;
+  if (dt == DT_BF16) {
+    const int split = wgrad_bf16_pick_split(w.M, Co, Ci, k * k);
+    if (int e = launch_wgrad_bf16(w, split, s)) return e;
+    return launch_wgrad_reduce(partial_ws, dW, (long long)Co * k * k * Ci, split, accumulate, s);
+  }
   const int split = wgrad_pick_split(w.M, Co, Ci, k * k);
   if (int e = launch_wgrad(w, split, s)) return e;
   return launch_wgrad_reduce(partial_ws, dW, (long long)Co * k * k * Ci, split, accumulate, s);
 }
 
-size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dt) {
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
-  const int split = wgrad_pick_split(N * Ho * Wo, Co, Ci, k * k);
+  const int split = dt == DT_BF16 ? wgrad_bf16_pick_split(N * Ho * Wo, Co, Ci, k * k) : wgrad_pick_split(N * Ho * Wo, Co, Ci, k * k);
   return (size_t)split * Co * k * k * Ci;
 }
 
@@ -321,7 +337,7 @@ static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   TRY(conv_forward_launch(X, W, Y, partial, nullptr, N_eff, Hi_eff, Wi_eff, Ci_eff, L.Co, k_eff, stride_eff, pad_eff,
-                          c.training ? EPI_STATS : 0, c.s));
+                          c.training ? EPI_STATS : 0, c.dt, c.s));
   const float* gamma = c.params + L.gamma_off;
   const float* beta = c.params + L.beta_off;
   if (c.training) {
@@ -336,15 +352,23 @@ static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float
   return 0;
 }
 
+// forward weight operand of layer L: the fp32 master, or its slice of the bf16 image made at the top of plan_forward
+static const float* fwd_weights(Ctx& c, const ConvSpec& L) {
+  if (c.dt != DT_BF16) return c.params + L.w_off;
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(c.arena + c.P.w16_off) + L.w_off * 2);
+}
+
 static int conv_bn(Ctx& c, const ConvSpec& L, const float* X) {
-  return conv_bn_coeffs(c, L, X, c.params + L.w_off, L.Ci, L.k, L.stride, L.pad, L.Hi, L.Wi, c.P.F);
+  return conv_bn_coeffs(c, L, X, fwd_weights(c, L), L.Ci, L.k, L.stride, L.pad, L.Hi, L.Wi, c.P.F);
 }
 
 int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
                  hipStream_t s) {
-  Ctx c{P, params, nullptr, bufs, arena, s, training, 0};
+  Ctx c{P, params, nullptr, bufs, arena, s, training, 0, P.dtype};
   P.last_training = training;
   const int F = P.F;
+  const int dt = P.dtype;
+  if (dt == DT_BF16) TRY(launch_convert_bf16(params, arena + P.w16_off, P.n_params, s));   // bf16 image of every weight (45 MB for ResNet-50)
   // ---- stem: x/255 -> Normalize -> conv1 7x7/2 straight from the NCHW frames (csrc/conv.hip stem_fwd_kernel) ----
   const ConvSpec& L0 = P.convs[0];
   // normalised, channel-interleaved copy of the frames (0.6 MB/frame): read by the stem forward now and by its weight
@@ -353,7 +377,7 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   {
     float* partial = arena + P.partial_off;
     double* acc = reinterpret_cast<double*>(arena + P.acc_off);
-    TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, s));
+    TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, dt, s));
     if (training) {
       TRY(launch_bn_stats_reduce(partial, L0.stats_rows, 64, acc, s));
       TRY(launch_bn_finalize_rows(acc, L0.stats_rows, (long long)F * 12544, params + L0.gamma_off, params + L0.beta_off,
@@ -366,8 +390,8 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   }
   float* Z0 = arena + L0.Z_off;
   const long long rows0 = (long long)F * 112 * 112;
-  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, nullptr, s));
-  TRY(launch_maxpool_fwd(Z0, arena + P.P0_off, reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, s));
+  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, nullptr, dt, s));
+  TRY(launch_maxpool_fwd(Z0, arena + P.P0_off, reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, dt, s));
   // ---- residual stages ----
   for (const BlockSpec& B : P.blocks) {
     const float* Xin = arena + B.in_off;
@@ -378,7 +402,7 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
       if (j < B.nconv - 1) {
         const long long rows = (long long)F * L.Ho * L.Wo;
         TRY(launch_bn_act_fwd(arena + L.Y_off, coef(c, L, 2), coef(c, L, 3), nullptr, nullptr, nullptr, arena + L.Z_off, rows,
-                              L.Co, 1, nullptr, s));
+                              L.Co, 1, nullptr, dt, s));
         cur = arena + L.Z_off;
       }
     }
@@ -389,14 +413,14 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
       const ConvSpec& Ld = P.convs[B.ds];
       TRY(conv_bn(c, Ld, Xin));
       TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), arena + Ld.Y_off, coef(c, Ld, 2), coef(c, Ld, 3),
-                            arena + B.out_off, rows, B.Co, 1, mask, s));
+                            arena + B.out_off, rows, B.Co, 1, mask, dt, s));
     } else {
       TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), Xin, nullptr, nullptr, arena + B.out_off, rows,
-                            B.Co, 1, mask, s));
+                            B.Co, 1, mask, dt, s));
     }
   }
   const BlockSpec& last = P.blocks.back();
-  TRY(launch_avgpool_fwd(arena + last.out_off, h_out, F, last.Ho * last.Wo, last.Co, s));
+  TRY(launch_avgpool_fwd(arena + last.out_off, h_out, F, last.Ho * last.Wo, last.Co, dt, s));
   return 0;
 }
 
@@ -407,25 +431,26 @@ static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigne
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   const float* Y = c.arena + L.Y_off;
-  TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.s));
+  TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.dt, c.s));
   const int prow = bn_bwd_partial_rows(rows, L.Co);
   TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
   TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
                                   coef(c, L, 5), c.accumulate, L.Co, c.s));
   TRY(launch_bn_bwd_apply(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
-                          dY, rows, L.Co, c.s));
+                          dY, rows, L.Co, c.dt, c.s));
   return 0;
 }
 
 static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
   return conv_wgrad_launch(X, dY, c.grads + L.w_off, c.arena + c.P.wgp_off, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad,
-                           c.accumulate, c.s);
+                           c.accumulate, c.dt, c.s);
 }
 
 static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const unsigned* addbits) {
   float* Wt = c.arena + c.P.wt_off;
-  TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
-  return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.s);
+  if (c.dt == DT_BF16) TRY(launch_transpose_w_bf16(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
+  else TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
+  return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.dt, c.s);
 }
 
 // Backward stages: 0 = avgpool + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem. The gradient w.r.t. the current
@@ -459,7 +484,8 @@ static int side_init(Plan& P) {
 
 int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
                   int accumulate, int* gd_io, hipStream_t s) {
-  Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate};
+  Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate, P.dtype};
+  const int dt = P.dtype;
   TRY(side_init(P));
   const bool side_on = P.use_side && P.side;
   Ctx cs = c;                       // context whose launches go to the side stream
@@ -516,7 +542,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       for (int r = 0; r < 5; ++r) role[r] = r;
       P.a_next = 0;
       P.wg_pending[0] = P.wg_pending[1] = false;
-      TRY(launch_avgpool_bwd(dh, Gp(0), F, last.Ho * last.Wo, last.Co, s));
+      TRY(launch_avgpool_bwd(dh, Gp(0), F, last.Ho * last.Wo, last.Co, dt, s));
     }
     for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
       const BlockSpec& B = P.blocks[bi];
@@ -569,10 +595,10 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       const ConvSpec& L0 = P.convs[0];
       float* Gb = Gp(3);
       float* Gc = Gp(4);
-      TRY(launch_maxpool_bwd(Gp(0), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Gb, F, 112, 112, 64, s));
+      TRY(launch_maxpool_bwd(Gp(0), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Gb, F, 112, 112, 64, dt, s));
       TRY(bn_backward(c, L0, Gb, nullptr, Gc));
       TRY(join_side());   // the stem wgrad shares the split-K scratch with the side stream's wgrads
-      TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, s));
+      TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, dt, s));
     }
     TRY(join_side());     // a finished stage's gradients are complete on the main stream (all-reduce hook, Adam)
   }
@@ -582,6 +608,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
 
 // ---- accessors for the C ABI ----
 int plan_out_dim(Plan* P) { return P->D; }
+int plan_dtype(Plan* P) { return P->dtype; }
 long long plan_num_params(Plan* P) { return P->n_params; }
 long long plan_num_buffers(Plan* P) { return P->n_buffers; }
 long long plan_arena_floats(Plan* P) { return P->arena_floats; }

@@ -13,10 +13,10 @@
 namespace r3m {
 
 int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
-                        int Co, int k, int stride, int pad, int flags, hipStream_t s);
+                        int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s);
 int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
-                      int stride, int pad, int accumulate, hipStream_t s);
-size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
+                      int stride, int pad, int accumulate, int dt, hipStream_t s);
+size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dt);
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -164,8 +164,8 @@ static LangDims lang_dims(int B, int D, int H, int LD) {
   d.dA = take((long long)d.R * (d.K1 > H ? d.K1 : H));
   d.dB = take((long long)d.R * H);
   d.Wt = take((long long)H * d.K1);
-  long long wg = conv_wgrad_ws_floats(d.R, 1, 1, d.K1, H, 1, 1, 0);
-  const long long wg2 = conv_wgrad_ws_floats(d.R, 1, 1, H, H, 1, 1, 0);
+  long long wg = conv_wgrad_ws_floats(d.R, 1, 1, d.K1, H, 1, 1, 0, DT_F32);
+  const long long wg2 = conv_wgrad_ws_floats(d.R, 1, 1, H, H, 1, 1, 0, DT_F32);
   if (wg2 > wg) wg = wg2;
   d.wgp = take(wg);
   d.total = ws;
@@ -191,7 +191,7 @@ int langrew_forward(const float* alle, const float* feats, const int* perm, cons
   int K = d.K1;
   for (int l = 0; l < 4; ++l) {
     if (int e = conv_forward_launch(in, params + d.w[l], ws + d.Hh[l], nullptr, params + d.b[l], d.R, 1, 1, K, H, 1, 1, 0,
-                                    EPI_BIAS | EPI_RELU, s))
+                                    EPI_BIAS | EPI_RELU, DT_F32, s))
       return e;
     in = ws + d.Hh[l];
     K = H;
@@ -202,7 +202,7 @@ int langrew_forward(const float* alle, const float* feats, const int* perm, cons
 
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
-                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, hipStream_t s);
+                      int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s);
 
 // dscore [15B] -> parameter gradients (flat, same layout as params) and dalle += d/d alle. Needs the workspace left by
 // langrew_forward (X and the four hidden activations).
@@ -228,12 +228,12 @@ int langrew_backward(const float* dscore, const int* iperm, const float* params,
   for (int l = 3; l >= 0; --l) {
     const float* in = l == 0 ? ws + d.X : ws + d.Hh[l - 1];
     const int K = l == 0 ? d.K1 : H;
-    if (int e = conv_wgrad_launch(in, dz, grads + d.w[l], wgp, d.R, 1, 1, K, H, 1, 1, 0, accumulate, s)) return e;
+    if (int e = conv_wgrad_launch(in, dz, grads + d.w[l], wgp, d.R, 1, 1, K, H, 1, 1, 0, accumulate, DT_F32, s)) return e;
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, dz, (const float*)nullptr, grads + d.b[l], d.R, H,
                        accumulate);
     if (int e = check_launch("lang_bias_grad")) return e;
     if (int e = launch_transpose_w(params + d.w[l], Wt, H, 1, K, s)) return e;
-    if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, nullptr, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, s))
+    if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, nullptr, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, DT_F32, s))
       return e;
     float* t = dz; dz = nxt; nxt = t;
   }

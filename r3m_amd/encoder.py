@@ -61,9 +61,19 @@ class _EncoderFn(torch.autograd.Function):
         return None, None, None, None
 
 
+PRECISIONS = {"fp32": 0, "bf16": 1}   # R3M_DT_F32 / R3M_DT_BF16 (include/r3m_hip.h)
+
+
 class HipResNet(nn.Module):
-    def __init__(self, size):
+    """precision="fp32": everything fp32 (the reference's arithmetic). precision="bf16": activations and their gradients are
+    stored in bf16 and the convolutions run on the bf16 MFMA with fp32 accumulation; parameters, their gradients, BatchNorm
+    statistics and the output embedding stay fp32 (what torch.autocast(bfloat16) around the reference's encoder would do)."""
+
+    def __init__(self, size, precision="fp32"):
         super().__init__()
+        if precision not in PRECISIONS:
+            raise ValueError(f"HipResNet: precision {precision!r} (expected one of {sorted(PRECISIONS)})")
+        self.precision = precision
         table, n_params, n_buffers, out_dim = _tensor_table(size)
         self.size = size
         self.outdim = out_dim
@@ -224,7 +234,7 @@ class HipResNet(nn.Module):
     def _plan(self, F):
         h = self._plans.get(F)
         if h is None:
-            h = _lib.lib().r3m_resnet_create(self.size, F)
+            h = _lib.lib().r3m_resnet_create_dt(self.size, F, PRECISIONS[self.precision])
             if not h:
                 raise RuntimeError(_lib.last_error())
             self._plans[F] = h

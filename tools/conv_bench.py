@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Micro-benchmark of single conv launches through the C ABI (GPU only). usage: conv_bench.py [fwd|wgrad] N,H,Ci,Co,k,s,p ..."""
+"""Micro-benchmark of single conv launches through the C ABI (GPU only).
+usage: conv_bench.py [fwd|wgrad|fwd16|wgrad16] N,H,Ci,Co,k,s,p ...      (the *16 modes run the bf16 kernels)"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -7,24 +8,30 @@ from r3m_amd import _lib
 
 L = _lib.lib()
 mode = sys.argv[1]
+bf16 = mode.endswith("16")
+if bf16:
+    mode = mode[:-2]
 for spec in sys.argv[2:]:
     N, H, Ci, Co, k, s, p = [int(v) for v in spec.split(",")]
     Ho = (H + 2 * p - k) // s + 1
     x = torch.randn((N, H, H, Ci), device="cuda")
     w = torch.randn((Co, k, k, Ci), device="cuda") * 0.05
     y = torch.empty((N, Ho, Ho, Co), device="cuda")
+    if bf16:
+        x, w, y = x.bfloat16(), w.bfloat16(), y.bfloat16()
+    dt = 1 if bf16 else 0
     st = torch.cuda.current_stream().cuda_stream
     flops = 2.0 * N * Ho * Ho * Co * Ci * k * k
     if mode == "fwd":
         rows = L.r3m_conv2d_stats_rows(N, H, H, Co, k, s, p)
         stats = torch.empty((rows, 2, Co), device="cuda")
-        fn = lambda: L.r3m_conv2d_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, st)
+        fn = lambda: L.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, dt, st)
     else:
         dy = torch.randn_like(y)
-        dw = torch.empty_like(w)
-        wsb = L.r3m_conv2d_wgrad_workspace_bytes(N, H, H, Ci, Co, k, s, p)
+        dw = torch.empty(w.shape, device="cuda")
+        wsb = L.r3m_conv2d_wgrad_workspace_bytes_dt(N, H, H, Ci, Co, k, s, p, dt)
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-        fn = lambda: L.r3m_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, 0, st)
+        fn = lambda: L.r3m_conv2d_wgrad_dt(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, 0, dt, st)
     for _ in range(3):
         assert fn() == 0, L.r3m_last_error()
     torch.cuda.synchronize()
@@ -37,4 +44,4 @@ for spec in sys.argv[2:]:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     M = N * Ho * Ho
-    print(f"{mode} {spec:28s} M={M:9d} ms={ms:8.3f} TF/s={flops/ms/1e9:7.1f}  tiles128={-(-M//128)*max(1,Co//128)} rounds={-(-M//128)*max(1,Co//128)/768:.3f}")
+    print(f"{mode}{'16' if bf16 else ''} {spec:28s} M={M:9d} ms={ms:8.3f} TF/s={flops/ms/1e9:7.1f}  tiles128={-(-M//128)*max(1,Co//128)} rounds={-(-M//128)*max(1,Co//128)/768:.3f}")
