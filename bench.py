@@ -25,6 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 GFLOP_PER_FRAME = {50: 24.2868, 34: 21.7435, 18: 10.6453}   # algorithmic conv FLOPs fwd+bwd, SURVEY.md §8(d)
 PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0                               # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), not the 2:1-sparse figure
 KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
           "wgrad_64x64"]
 
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--size", type=int, default=50)
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="clips per GPU (5 frames each); BASELINE bs=256")
     ap.add_argument("--langweight", type=float, default=0.0, help="> 0: BASELINE configs[2] (language head on frozen text features)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: BASELINE configs[2]/[4] (bf16 activations + bf16 MFMA, fp32 masters/statistics); default = headline fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
@@ -101,7 +104,7 @@ def main():
     torch.manual_seed(1)                               # config_rep.yaml seed
     B = args.clips_per_gpu
     model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=args.langweight, tcnweight=1.0,
-                l2dist=True, bs=B)
+                l2dist=True, bs=B, precision=args.precision)
     model = model.to(dev)
     net = make_network_wrapper(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -148,8 +151,10 @@ def main():
                                 "tflops": flops[k] / (ms[k] * 1e-3) / 1e12})
         dom = max(range(4), key=lambda k: ms[k])
         ach = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        bf16 = args.precision == "bf16"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest_bf16.json" if bf16 else "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get("dominant_kernel_hbm_bytes_per_launch")
@@ -160,16 +165,17 @@ def main():
                       f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2 bs={B}/GPU",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), fp32, "
+            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{2 if bf16 else 1}]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), "
+                                   f"{'bf16 activations / bf16 MFMA, fp32 master weights + statistics + Adam' if bf16 else 'fp32'}, "
                                    f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist",
                        "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
                        "final_full_loss": metrics["full_loss"]},
-            "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
                          "algorithmic_gflop_per_launch": round(flops[dom] / max(1, launches[dom]) / 1e9, 3),
-                         "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[args.size] / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[args.size] / 1e3 / peak, 4),
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:

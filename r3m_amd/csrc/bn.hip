@@ -171,6 +171,58 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Y
   }
 }
 
+// ---- bf16 variants: 8 elements (16 bytes) per lane, same arithmetic per element as the 4-wide kernels ----
+struct f32x8 { f32x4 lo, hi; };
+__device__ __forceinline__ f32x8 ld8(const bf16_t* p) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  f32x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r.lo[e] = (float)v[e]; r.hi[e] = (float)v[4 + e]; }
+  return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f32x8& v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)v.lo[e]; o[4 + e] = (bf16_t)v.hi[e]; }
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ f32x8 ld8f(const float* p) { f32x8 r; r.lo = ld4(p); r.hi = ld4(p + 4); return r; }
+#define FOR8(v, expr_lo, expr_hi) _Pragma("unroll") for (int e = 0; e < 4; ++e) { v.lo[e] = (expr_lo); v.hi[e] = (expr_hi); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const bf16_t* __restrict__ Y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const bf16_t* __restrict__ R,
+                                                            const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                            bf16_t* __restrict__ Z, long long n8, int c8mask, int relu,
+                                                            unsigned* __restrict__ maskbits) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;   // n8 is a multiple of 4 when maskbits is used: a 4-lane word group is all in or all out
+  const int c = ((int)(i & c8mask)) * 8;
+  const f32x8 y = ld8(Y + i * 8);
+  const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c);
+  f32x8 z;
+  FOR8(z, fmaf(y.lo[e], sc.lo[e], sh.lo[e]), fmaf(y.hi[e], sc.hi[e], sh.hi[e]))
+  if (MODE == 1) {
+    const f32x8 r = ld8(R + i * 8);
+    FOR8(z, z.lo[e] + r.lo[e], z.hi[e] + r.hi[e])
+  } else if (MODE == 2) {
+    const f32x8 y2 = ld8(R + i * 8);
+    const f32x8 sc2 = ld8f(scale2 + c), sh2 = ld8f(shift2 + c);
+    FOR8(z, z.lo[e] + fmaf(y2.lo[e], sc2.lo[e], sh2.lo[e]), z.hi[e] + fmaf(y2.hi[e], sc2.hi[e], sh2.hi[e]))
+  }
+  if (relu) { FOR8(z, fmaxf(z.lo[e], 0.f), fmaxf(z.hi[e], 0.f)) }
+  st8(Z + i * 8, z);
+  if (maskbits) {
+    // same bit layout as the 4-wide kernel (element j of the tensor = bit j & 31 of word j >> 5): this lane owns byte i & 3
+    unsigned v = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v |= ((z.lo[e] > 0.f) ? (1u << e) : 0u) | ((z.hi[e] > 0.f) ? (16u << e) : 0u);
+    v <<= 8 * (threadIdx.x & 3);
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2);
+    if ((threadIdx.x & 3) == 0) maskbits[i >> 2] = v;
+  }
+}
+
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, const void* Rv, const float* scale2,
@@ -180,6 +232,20 @@ int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, co
   const long long n4 = rows * C / 4;
   const int grid = ceil_div(n4, 256);
   const int c4mask = C / 4 - 1;
+  if (dt == DT_BF16 && C >= 8) {
+    const bf16_t* Y = static_cast<const bf16_t*>(Yv);
+    const bf16_t* R = static_cast<const bf16_t*>(Rv);
+    bf16_t* Z = static_cast<bf16_t*>(Zv);
+    const long long n8 = rows * C / 8;
+    const int g8 = ceil_div(n8, 256), c8mask = C / 8 - 1;
+    if (R && scale2)
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<2>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+    else if (R)
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<1>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+    else
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<0>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+    return check_launch("bn_act_fwd16");
+  }
   DT_DISPATCH(dt, "bn_act_fwd", {
     const T* Y = static_cast<const T*>(Yv);
     const T* R = static_cast<const T*>(Rv);
@@ -256,6 +322,62 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
+// bf16: a thread keeps 8 channels; block = RB rows x up to 2048 channels
+__global__ __launch_bounds__(256) void bn_bwd_reduce16_kernel(const bf16_t* __restrict__ dZ, const unsigned* __restrict__ Zbits,
+                                                               const bf16_t* __restrict__ Y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float* __restrict__ partials,
+                                                               long long rows, int C, int cpb8, int rows_per_block) {
+  __shared__ f32x4 red[4][256];
+  const int tcol = threadIdx.x % cpb8, trow = threadIdx.x / cpb8;
+  const int rpp = 256 / cpb8;
+  const int c = (blockIdx.y * cpb8 + tcol) * 8;
+  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c), mu = ld8f(mean + c), is = ld8f(invstd + c);
+  f32x8 s1, s2;
+  FOR8(s1, 0.f, 0.f)
+  FOR8(s2, 0.f, 0.f)
+  for (long long r = r_begin + trow; r < r_end; r += rpp) {
+    const long long off = r * C + c;
+    const f32x8 y = ld8(Y + off);
+    const f32x8 dz = ld8(dZ + off);
+    f32x8 g;
+    if (Zbits) {
+      const unsigned nb = (Zbits[off >> 5] >> (int)(off & 31)) & 255u;
+      FOR8(g, ((nb >> e) & 1u) ? dz.lo[e] : 0.f, ((nb >> (4 + e)) & 1u) ? dz.hi[e] : 0.f)
+    } else {
+      FOR8(g, fmaf(y.lo[e], sc.lo[e], sh.lo[e]) > 0.f ? dz.lo[e] : 0.f, fmaf(y.hi[e], sc.hi[e], sh.hi[e]) > 0.f ? dz.hi[e] : 0.f)
+    }
+    FOR8(s1, s1.lo[e] + g.lo[e], s1.hi[e] + g.hi[e])
+    FOR8(s2, fmaf(g.lo[e], (y.lo[e] - mu.lo[e]) * is.lo[e], s2.lo[e]), fmaf(g.hi[e], (y.hi[e] - mu.hi[e]) * is.hi[e], s2.hi[e]))
+  }
+  red[0][threadIdx.x] = s1.lo; red[1][threadIdx.x] = s1.hi;
+  red[2][threadIdx.x] = s2.lo; red[3][threadIdx.x] = s2.hi;
+  __syncthreads();
+  if (trow == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s1.lo += red[0][k * cpb8 + tcol]; s1.hi += red[1][k * cpb8 + tcol];
+      s2.lo += red[2][k * cpb8 + tcol]; s2.hi += red[3][k * cpb8 + tcol];
+    }
+    float* p1 = partials + ((long long)blockIdx.x * 2 + 0) * C + c;
+    float* p2 = partials + ((long long)blockIdx.x * 2 + 1) * C + c;
+    st4(p1, s1.lo); st4(p1 + 4, s1.hi);
+    st4(p2, s2.lo); st4(p2 + 4, s2.hi);
+  }
+}
+
+static inline bool use_v8(int dt, int C) { return dt == DT_BF16 && C % 8 == 0; }
+
+static inline void bwd_geometry16(long long rows, int C, int* cpb8, int* rpb, int* nblk) {
+  int c8 = C / 8;
+  *cpb8 = c8 < 256 ? c8 : 256;
+  const int rpp = 256 / *cpb8;
+  *rpb = 32 * rpp;
+  *nblk = ceil_div(rows, *rpb);
+}
+
 static inline void bwd_geometry(long long rows, int C, int* cpb4, int* rpb, int* nblk) {
   int c4 = C / 4;
   *cpb4 = c4 < 256 ? c4 : 256;
@@ -264,9 +386,10 @@ static inline void bwd_geometry(long long rows, int C, int* cpb4, int* rpb, int*
   *nblk = ceil_div(rows, *rpb);
 }
 
-int bn_bwd_partial_rows(long long rows, int C) {
-  int cpb4, rpb, nblk;
-  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+int bn_bwd_partial_rows(long long rows, int C, int dt) {
+  int cpb, rpb, nblk;
+  if (use_v8(dt, C)) bwd_geometry16(rows, C, &cpb, &rpb, &nblk);
+  else bwd_geometry(rows, C, &cpb, &rpb, &nblk);
   return nblk;
 }
 
@@ -275,6 +398,13 @@ int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbit
                          int dt, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce: C=%d must be a power of two >= 4", C);
   int cpb4, rpb, nblk;
+  if (use_v8(dt, C) && !Zmask) {
+    bwd_geometry16(rows, C, &cpb4, &rpb, &nblk);
+    hipLaunchKernelGGL(bn_bwd_reduce16_kernel, dim3(nblk, ceil_div(C / 8, cpb4)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
+                       static_cast<const bf16_t*>(Y), scale, shift, mean, invstd, partials, rows, C, cpb4, rpb);
+    return check_launch("bn_bwd_reduce16");
+  }
+  R3M_REQUIRE(!use_v8(dt, C), "bn_bwd_reduce(bf16): pass the 1-bit mask (zbits) or no mask; a bf16 zmask tensor is not supported");
   bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
   DT_DISPATCH(dt, "bn_bwd_reduce",
               hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s,
@@ -345,10 +475,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   st4t(dY + i * 4, o);
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const bf16_t* __restrict__ dZ, const unsigned* __restrict__ Zbits,
+                                                              const bf16_t* __restrict__ Y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                              const float* __restrict__ c2, bf16_t* __restrict__ dY, long long n8,
+                                                              int c8mask) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int c = ((int)(i & c8mask)) * 8;
+  const f32x8 y = ld8(Y + i * 8);
+  const f32x8 dz = ld8(dZ + i * 8);
+  const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c), mu = ld8f(mean + c), is = ld8f(invstd + c);
+  const f32x8 k1 = ld8f(c1 + c), k2 = ld8f(c2 + c);
+  f32x8 g;
+  if (Zbits) {
+    const unsigned nb = (Zbits[i >> 2] >> (8 * (int)(i & 3))) & 255u;
+    FOR8(g, ((nb >> e) & 1u) ? dz.lo[e] : 0.f, ((nb >> (4 + e)) & 1u) ? dz.hi[e] : 0.f)
+  } else {
+    FOR8(g, fmaf(y.lo[e], sc.lo[e], sh.lo[e]) > 0.f ? dz.lo[e] : 0.f, fmaf(y.hi[e], sc.hi[e], sh.hi[e]) > 0.f ? dz.hi[e] : 0.f)
+  }
+  f32x8 o;
+  FOR8(o, sc.lo[e] * (g.lo[e] - k1.lo[e] - ((y.lo[e] - mu.lo[e]) * is.lo[e]) * k2.lo[e]),
+       sc.hi[e] * (g.hi[e] - k1.hi[e] - ((y.hi[e] - mu.hi[e]) * is.hi[e]) * k2.hi[e]))
+  st8(dY + i * 8, o);
+}
+
 int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dY,
                         long long rows, int C, int dt, hipStream_t s) {
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_apply: C=%d must be a power of two >= 4", C);
+  if (use_v8(dt, C) && !Zmask) {
+    const long long n8 = rows * C / 8;
+    hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
+                       static_cast<const bf16_t*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<bf16_t*>(dY), n8, C / 8 - 1);
+    return check_launch("bn_bwd_apply16");
+  }
   const long long n4 = rows * C / 4;
   DT_DISPATCH(dt, "bn_bwd_apply",
               hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, static_cast<const T*>(dZ),

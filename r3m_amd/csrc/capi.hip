@@ -262,7 +262,7 @@ int r3m_stem_conv_wgrad(const float* xn, const float* dy, float* dw_ohwi, void* 
 
 // workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
 static size_t bn_acc_off(long long rows, int C) {
-  size_t p = (size_t)bn_bwd_partial_rows(rows, C) * 2 * C * 4;
+  size_t p = (size_t)bn_bwd_partial_rows(rows, C, DT_F32) * 2 * C * 4;   // the fp32 geometry has the most rows
   return (p + 255) / 256 * 256;
 }
 static size_t bn_c12_off(long long rows, int C) { return bn_acc_off(rows, C) + (size_t)64 * 2 * C * 8; }
@@ -301,7 +301,7 @@ int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, cons
   float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
   if (int e = launch_bn_bwd_reduce(dz, zmask, zbits, y, scale, shift, mean, invstd, partial, rows, C, dtype, S(stream))) return e;
-  const int prow = bn_bwd_partial_rows(rows, C);
+  const int prow = bn_bwd_partial_rows(rows, C, dtype);
   if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
   if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
   return launch_bn_bwd_apply(dz, zmask, zbits, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, dtype, S(stream));

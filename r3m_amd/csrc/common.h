@@ -114,7 +114,7 @@ int launch_bn_eval_coeffs(const float* gamma, const float* beta, const float* ru
 // activation tensors are void*: fp32 (dt = DT_F32) or bf16 (DT_BF16); coefficients / partials / statistics are fp32
 int launch_bn_act_fwd(const void* Y, const float* scale, const float* shift, const void* R, const float* scale2,
                       const float* shift2, void* Z, long long rows, int C, int relu, unsigned* maskbits, int dt, hipStream_t s);
-int bn_bwd_partial_rows(long long rows, int C);
+int bn_bwd_partial_rows(long long rows, int C, int dt);
 int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
                          int dt, hipStream_t s);

@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the stages
 
-  gg_epilogue<BM, BN, WM, WN, EPI, 2 * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
+  if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
+  if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, 2 * STAGE / 4>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+  else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, 2 * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
 }
 
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }

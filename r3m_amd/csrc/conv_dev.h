@@ -37,22 +37,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
-// Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
-// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
-// compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
-template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS, class OT = float>
-__device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                            int m0, int n0, int mt) {
+// BatchNorm partials of one block tile: per-column sum / sum of squares over the block's rows -> stats[mt][2][Nc]
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gg_stats(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, int n0,
+                                         int mt) {
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int lrow = lane & 31;
-
-  if (EPI & EPI_STATS) {
+  {
     // rows >= M were staged as zeros -> their accumulators are exactly 0 and add nothing to either sum
     float* red = smem;  // [WM][2][BN]; the K loop ended with a barrier, the tiles are dead
 #pragma unroll
@@ -90,6 +85,24 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
     }
     __syncthreads();
   }
+}
+
+// ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
+// Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
+// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
+// compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
+template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS, class OT = float>
+__device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                            int m0, int n0, int mt) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 31;
+
+  if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, smem, n0, mt);
 
   constexpr int CW = TN * 32;          // columns owned by the wave
   constexpr int CS = CW + 4;           // padded slab row stride (floats)
@@ -154,6 +167,86 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
           for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
         }
         st4t(dst, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// bf16 output variant of the store part: 8 columns (16 bytes) per lane. EPI: 0 / EPI_ACCUM / EPI_MASKED_ADD (with the 1-bit
+// mask, or a bf16 activation as the mask source).
+template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS>
+__device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                              int m0, int n0) {
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int CW = TN * 32;          // columns owned by the wave
+  constexpr int CS = CW + 4;           // padded slab row stride (floats)
+  constexpr int F8 = CW / 8;           // 16-byte stores per slab row
+  constexpr int RPI = 64 / F8;         // rows covered per store instruction
+  static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = lane & 31;
+  float* slab = smem + wave * 32 * CS;
+  const bool out_simple = (p.os == 1);
+  const int hwg = p.Hg * p.Wg;
+  const int ecol = (lane % F8) * 8;
+  const int erow = lane / F8;
+  const int gcol = n0 + wn * CW + ecol;
+  bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int lr = it * RPI + erow;
+      const int row = m0 + (wm * TM + tm) * 32 + lr;
+      if (row < p.M && gcol < p.Nc) {
+        long long roff;
+        if (out_simple) {
+          roff = (long long)row * p.Nc;
+        } else {
+          const int n = row / hwg;
+          const int rem = row - n * hwg;
+          const int gy = rem / p.Wg;
+          const int gx = rem - gy * p.Wg;
+          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
+        }
+        const long long eo = roff + gcol;      // element offset, multiple of 8
+        float v[8];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+        if (EPI & EPI_ACCUM) {
+          const bf16x8 o = *reinterpret_cast<const bf16x8*>(outp + eo);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+        }
+        if (EPI & EPI_MASKED_ADD) {
+          const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eo);
+          if (p.addbits) {
+            const unsigned nb = (p.addbits[eo >> 5] >> (int)(eo & 31)) & 255u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ((nb >> e) & 1u) ? (float)g[e] : 0.f;
+          } else {
+            const bf16x8 z = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add1) + eo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ((float)z[e] > 0.f) ? (float)g[e] : 0.f;
+          }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(outp + eo) = o;
       }
     }
     __syncthreads();

