@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--langweight", type=float, default=0.0, help="> 0: BASELINE configs[2] (language head on frozen text features)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: BASELINE configs[2]/[4] (bf16 activations + bf16 MFMA, fp32 masters/statistics); default = headline fp32")
+    ap.add_argument("--doaug", choices=["none", "rctraj", "rc"], default="none",
+                    help="rctraj/rc: BASELINE configs[4] — every step starts from resident uint8 256x256 clips and runs the on-GPU "
+                         "RandomResizedCrop(224) (csrc/augment.hip) inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
@@ -108,7 +111,14 @@ def main():
     model = model.to(dev)
     net = make_network_wrapper(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
+    if args.doaug == "none":
+        frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
+        get_frames = lambda: frames
+    else:
+        from r3m_amd import augment
+        raw = torch.randint(0, 256, (B, 5, 3, 256, 256), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+        box_gen = torch.Generator().manual_seed(99 + rank)
+        get_frames = lambda: augment.random_resized_crop(raw, per_clip=(args.doaug == "rctraj"), generator=box_gen)
     langs = [""] * B
     if args.langweight > 0:   # frozen DistilBERT stand-in: [B,768] N(0,1)*0.3, all clips have language
         gl = torch.Generator(device=dev).manual_seed(4321 + rank)
@@ -121,14 +131,14 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        trainer.update(net, (frames, langs), i)
+        trainer.update(net, (get_frames(), langs), i)
     L.r3m_profile_enable(1)
     if args.launch_csv and rank == 0:
         _lib.check(L.r3m_profile_dump_to(args.launch_csv.encode()), "profile_dump_to")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        metrics, _ = trainer.update(net, (frames, langs), args.warmup + i)
+        metrics, _ = trainer.update(net, (get_frames(), langs), args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     ms, launches, flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
@@ -166,9 +176,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{2 if bf16 else 1}]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), "
+            "config": {"workload": f"BASELINE configs[{(4 if args.size == 34 else 2) if bf16 else (3 if world > 1 else 1)}]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), "
                                    f"{'bf16 activations / bf16 MFMA, fp32 master weights + statistics + Adam' if bf16 else 'fp32'}, "
-                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist",
+                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist doaug={args.doaug}",
                        "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
                        "final_full_loss": metrics["full_loss"]},
             "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": peak,

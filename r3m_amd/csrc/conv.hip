@@ -558,6 +558,11 @@ static int gg_use_glds() {
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
   if (p.dtype == DT_BF16) {
+    {
+      static int dbg = -1;
+      if (dbg < 0) { const char* e = getenv("R3M_GG_DEBUG"); dbg = e ? atoi(e) : 0; }
+      p.debug = dbg;   // timing probes only (wrong results when != 0)
+    }
     R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
     R3M_REQUIRE(p.M > 0 && p.Nc > 0, "gather_gemm: empty problem M=%d Nc=%d", p.M, p.Nc);
     for (int t = 0; t < p.ntaps; ++t)

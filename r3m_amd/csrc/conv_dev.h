@@ -174,82 +174,106 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
 }
 
 // bf16 output variant of the store part: 8 columns (16 bytes) per lane. EPI: 0 / EPI_ACCUM / EPI_MASKED_ADD (with the 1-bit
-// mask, or a bf16 activation as the mask source).
+// mask, or a bf16 activation as the mask source). Each wave transposes its 64 x 64 accumulators through a PRIVATE LDS slab,
+// so no block barrier is needed (a wave's own LDS accesses execute in order): waves drain independently, which matters
+// because for the 1x1 convolutions with few K tiles the epilogue is more than half of a block's lifetime.
+// Plain stores round to bf16 BEFORE the transposition (slab of bf16, one pass over all rows); the read-modify-write
+// variants keep an fp32 slab (two passes of 32 rows) so that the sum is rounded once.
 template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS>
 __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               int m0, int n0) {
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int CW = TN * 32;          // columns owned by the wave
-  constexpr int CS = CW + 4;           // padded slab row stride (floats)
   constexpr int F8 = CW / 8;           // 16-byte stores per slab row
   constexpr int RPI = 64 / F8;         // rows covered per store instruction
-  static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
+  constexpr bool RMW = (EPI & (EPI_ACCUM | EPI_MASKED_ADD)) != 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane & 31;
-  float* slab = smem + wave * 32 * CS;
   const bool out_simple = (p.os == 1);
   const int hwg = p.Hg * p.Wg;
   const int ecol = (lane % F8) * 8;
   const int erow = lane / F8;
   const int gcol = n0 + wn * CW + ecol;
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+  auto row_off = [&](int row) -> long long {
+    if (out_simple) return (long long)row * p.Nc;
+    const int n = row / hwg;
+    const int rem = row - n * hwg;
+    const int gy = rem / p.Wg;
+    const int gx = rem - gy * p.Wg;
+    return (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
+  };
+  if constexpr (!RMW) {
+    constexpr int CSH = CW + 8;          // slab row stride in bf16 (16-byte aligned rows, 4-bank skew)
+    static_assert(WM * WN * TM * 32 * CSH * 2 <= SMEM_FLOATS * 4, "epilogue slab must fit in the operand tiles' LDS");
+    bf16_t* slab = reinterpret_cast<bf16_t*>(smem) + wave * TM * 32 * CSH;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
-    __syncthreads();
+        for (int r = 0; r < 16; ++r)
+          slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[tm][tn][r];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+    for (int it = 0; it < TM * 32 / RPI; ++it) {
       const int lr = it * RPI + erow;
-      const int row = m0 + (wm * TM + tm) * 32 + lr;
-      if (row < p.M && gcol < p.Nc) {
-        long long roff;
-        if (out_simple) {
-          roff = (long long)row * p.Nc;
-        } else {
-          const int n = row / hwg;
-          const int rem = row - n * hwg;
-          const int gy = rem / p.Wg;
-          const int gx = rem - gy * p.Wg;
-          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
-        }
-        const long long eo = roff + gcol;      // element offset, multiple of 8
-        float v[8];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-        if (EPI & EPI_ACCUM) {
-          const bf16x8 o = *reinterpret_cast<const bf16x8*>(outp + eo);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
-        }
-        if (EPI & EPI_MASKED_ADD) {
-          const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eo);
-          if (p.addbits) {
-            const unsigned nb = (p.addbits[eo >> 5] >> (int)(eo & 31)) & 255u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += ((nb >> e) & 1u) ? (float)g[e] : 0.f;
-          } else {
-            const bf16x8 z = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add1) + eo);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += ((float)z[e] > 0.f) ? (float)g[e] : 0.f;
-          }
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-        *reinterpret_cast<bf16x8*>(outp + eo) = o;
-      }
+      const int row = m0 + wm * TM * 32 + lr;
+      if (row < p.M && gcol < p.Nc)
+        *reinterpret_cast<bf16x8*>(outp + row_off(row) + gcol) = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
     }
-    __syncthreads();
+  } else {
+    constexpr int CS = CW + 4;           // padded slab row stride (floats)
+    static_assert(WM * WN * 32 * CS <= SMEM_FLOATS, "epilogue slab must fit in the operand tiles' LDS");
+    float* slab = smem + wave * 32 * CS;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int lr = it * RPI + erow;
+        const int row = m0 + (wm * TM + tm) * 32 + lr;
+        if (row < p.M && gcol < p.Nc) {
+          const long long eo = row_off(row) + gcol;      // element offset, multiple of 8
+          float v[8];
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          if (EPI & EPI_ACCUM) {
+            const bf16x8 o = *reinterpret_cast<const bf16x8*>(outp + eo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+          }
+          if (EPI & EPI_MASKED_ADD) {
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eo);
+            if (p.addbits) {
+              const unsigned nb = (p.addbits[eo >> 5] >> (int)(eo & 31)) & 255u;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += ((nb >> e) & 1u) ? (float)g[e] : 0.f;
+            } else {
+              const bf16x8 z = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add1) + eo);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += ((float)z[e] > 0.f) ? (float)g[e] : 0.f;
+            }
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(outp + eo) = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
