@@ -80,6 +80,8 @@ struct WgradParams {
   int tilesN;          // ceil(Ci / BN)
   int interleave;      // 1: spread the next K step's DMA pieces between this step's MFMAs (set by the launcher)
   int dtype;           // DT_F32 / DT_BF16 storage of dY and X (out is always fp32)
+  int gx;              // (co tile, ci tile, tap) blocks per split; the launch is 1-D: gx * splitK blocks
+  int xcd;             // 1: XCD-aware block order — all blocks of one split (same dY / X rows) run on ONE XCD and share its L2
 };
 
 // ---- launchers (conv.hip) ----

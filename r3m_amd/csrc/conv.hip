@@ -640,12 +640,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int T = p.KH * p.KW;
-  const int tap = blockIdx.x % T;  // the taps of one (co, ci) tile are neighbours: they re-read the same dY rows
-  const int tile = blockIdx.x / T;
+  const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bx = lid % p.gx, by = lid / p.gx;   // by = split index: consecutive logical blocks read the same rows
+  const int tap = bx % T;  // the taps of one (co, ci) tile are neighbours: they re-read the same dY rows
+  const int tile = bx / T;
   const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
   const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int ms = blockIdx.y * p.rows_per_split;
+  const int ms = by * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
 
   const int a_c = (tid % A_F4) * 4, a_r = tid / A_F4;
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
-  float* out = p.out + (long long)blockIdx.y * p.Co * T * p.Ci;
+  float* out = p.out + (long long)by * p.Co * T * p.Ci;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -811,12 +813,14 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WIDE ? 0 : (wave_s >> 1), wn = WIDE ? wave_s : (wave_s & 1);
   const int T = p.KH * p.KW;
-  const int tap = blockIdx.x % T;
-  const int tile = blockIdx.x / T;
+  const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bx = lid % p.gx, by = lid / p.gx;   // by = split index: consecutive logical blocks read the same rows
+  const int tap = bx % T;
+  const int tile = bx / T;
   const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
   const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int ms = blockIdx.y * p.rows_per_split;
+  const int ms = by * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   const int hw = p.Ho * p.Wo;
 
@@ -983,7 +987,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
     mfma_stage(fragA, fragB, -1);
   }
 
-  float* out = p.out + (long long)blockIdx.y * p.Co * T * p.Ci;
+  float* out = p.out + (long long)by * p.Co * T * p.Ci;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1283,20 +1287,25 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     static int il = -1;
     if (il < 0) { const char* e = getenv("R3M_WG_INTERLEAVE"); il = e ? atoi(e) : 0; }
     p.interleave = il;
+    static int xc = -1;
+    if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
+    p.xcd = xc;
   }
   const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * (p.Ci == 160 ? 147 : p.Ci);
   if (wg_wide(p.Co, p.Ci)) {
     p.tilesN = ceil_div(p.Ci, 128);
     const int tiles = ceil_div(p.Co, 128) * p.tilesN * T;
     prof_begin(KC_WGRAD_WIDE, flops, p.M, p.Co, p.Ci, T, s);
-    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    p.gx = tiles;
+    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
     prof_begin(KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
-    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles, splitK), dim3(256), 0, s, p);
+    p.gx = tiles;
+    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
   }
   prof_end(s);
   return check_launch("wgrad");

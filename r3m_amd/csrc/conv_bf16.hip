@@ -225,12 +225,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int T = p.KH * p.KW;
-  const int tap = blockIdx.x % T;
-  const int tile = blockIdx.x / T;
+  const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bx = lid % p.gx, by = lid / p.gx;   // by = split index: consecutive logical blocks read the same rows
+  const int tap = bx % T;
+  const int tile = bx / T;
   const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
   const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int ms = blockIdx.y * p.rows_per_split;
+  const int ms = by * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   const int hw = p.Ho * p.Wo;
   const char* dYb = reinterpret_cast<const char*>(p.dY);
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
     mfma_stage(smem + cur * STAGE, (kt + 1 < nk) ? (cur ^ 1) : -1);
   }
 
-  float* out = p.out + (long long)blockIdx.y * p.Co * T * p.Ci;
+  float* out = p.out + (long long)by * p.Co * T * p.Ci;
   const int lrow = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
@@ -419,7 +421,13 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   const int tilesM = wide ? p.Co / 128 : p.Co / 64;
   const double flops = 2.0 * (double)p.M * p.Co * (double)p.Ci * T;
   prof_begin(wide ? KC_WGRAD_WIDE : KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
-  const dim3 grid(tilesM * p.tilesN * T, splitK);
+  p.gx = tilesM * p.tilesN * T;
+  {
+    static int xc = -1;
+    if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
+    p.xcd = xc;
+  }
+  const dim3 grid(p.gx * splitK);
   if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, s, p);
   prof_end(s);

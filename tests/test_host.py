@@ -114,3 +114,22 @@ def test_detgen_is_stable():
     assert sorted(p.tolist()) == list(range(17))
     # pinned values: the generator must never drift (golden inputs are regenerated from it on the GPU box)
     np.testing.assert_allclose(detgen.unit("pin", 3), [0.2076382040977478, 0.2765554189682007, 0.4500434398651123], rtol=0, atol=1e-7)
+
+
+def test_precision_option_is_plumbed():
+    """`precision` is an extra constructor key on top of the reference's (models_r3m.py:17-19): default fp32, validated,
+    reachable from the config as agent.precision=bf16, and never changes the parameter / state-dict surface."""
+    import os
+    from r3m_amd import R3M, config
+    from r3m_amd.encoder import HipResNet
+    with pytest.raises(ValueError):
+        HipResNet(18, precision="fp16")
+    m32 = R3M("cpu", 1e-4, 64, size=18, langweight=0.0, tcnweight=1.0)
+    m16 = R3M("cpu", 1e-4, 64, size=18, langweight=0.0, tcnweight=1.0, precision="bf16")
+    assert m32.convnet.precision == "fp32" and m16.convnet.precision == "bf16"
+    sd32, sd16 = m32.state_dict(), m16.state_dict()
+    assert list(sd32.keys()) == list(sd16.keys())
+    assert all(sd16[k].dtype == sd32[k].dtype and sd16[k].shape == sd32[k].shape for k in sd32)   # fp32 masters in both
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.load_config(os.path.join(root, "r3m_amd", "cfgs", "config_rep.yaml"), ["agent.precision=bf16"])
+    assert cfg.agent.precision == "bf16"

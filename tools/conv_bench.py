@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Micro-benchmark of single conv launches through the C ABI (GPU only).
 usage: conv_bench.py [fwd|wgrad|fwd16|wgrad16] N,H,Ci,Co,k,s,p ...      (the *16 modes run the bf16 kernels)"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from r3m_amd import _lib
 
 L = _lib.lib()
