@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--doaug", choices=["none", "rctraj", "rc"], default="none",
                     help="rctraj/rc: BASELINE configs[4] — every step starts from resident uint8 256x256 clips and runs the on-GPU "
                          "RandomResizedCrop(224) (csrc/augment.hip) inside the timed region")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the conv GEMM launches with HIP events (diagnostic: "
+                                                                     "measures what the live roofline timing costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
@@ -132,7 +134,7 @@ def main():
 
     for i in range(args.warmup):
         trainer.update(net, (get_frames(), langs), i)
-    L.r3m_profile_enable(1)
+    L.r3m_profile_enable(0 if args.no_kernel_timing else 1)
     if args.launch_csv and rank == 0:
         _lib.check(L.r3m_profile_dump_to(args.launch_csv.encode()), "profile_dump_to")
     barrier()

@@ -1110,7 +1110,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
     __syncthreads();
-    gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS, OT>(p, acc, smem, blk * 256, 0, blk);   // ends with a barrier
+    gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS, OT>(p, acc, smem, blk * 256, 0, blk);
+    __syncthreads();   // the epilogue slabs alias the patch that the next iteration refills
   }
 }
 

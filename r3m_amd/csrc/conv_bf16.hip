@@ -35,18 +35,26 @@ __device__ __forceinline__ void dma16(const char* src, unsigned char* lds) {
 }
 
 // =====================================================================================================
-// gather-GEMM on bf16 operands. Block BM x BN, K step 64 (one 128-byte row per GEMM row), 4 waves as WM x WN, each wave
-// 2 x 2 MFMA tiles. Two LDS stages; tile t+1's DMA is issued right after the barrier that publishes tile t, its pieces
-// spread between tile t's MFMAs.
+// gather-GEMM on bf16 operands. Block BM x BN, K step 64 (one 128-byte row per GEMM row), WM x WN waves.
+// LDS: a ring of NST stages of {A[BM][64], B[BN][64]} bf16 (dynamic LDS, NST * (BM+BN) * 128 bytes). Tile t + NST - 1 is
+// issued (DMA pieces spread between the MFMA groups of tile t) right after the barrier that publishes tile t, so up to
+// NST - 1 tiles are in flight per block; a wave waits only for ITS pieces of the oldest tile (s_waitcnt vmcnt(pieces of the
+// newer tile), loads retire in order). Two configurations are used:
+//   4 waves, 2 stages (64 KB, 2 blocks/CU)   — the production configuration
+//   8 waves, 3 stages (96-120 KB, 1 block/CU) — experiment (R3M_BF16_RING): the L2 -> LDS DMA path itself delivers 17 TB/s
+//     with 8 waves x 8 KB outstanding per CU (tools/micro/l2dma.hip) against the ~6 TB/s these kernels draw, but one block
+//     per CU loses more in uncovered prologue/epilogue than the deeper ring wins
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmParams p) {
+template <int BM, int BN, int WM, int WN, int EPI, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const GatherGemmParams p) {
+  constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(TM == 2 && TN == 2, "wave tile is 64 x 64");
-  constexpr int AJ = BM / 32, BJ = BN / 32;             // DMA instructions per wave per tile (8 rows each)
+  constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);  // DMA instructions per wave per tile (8 rows each)
+  static_assert(AJ * 8 * NW == BM && BJ * 8 * NW == BN, "every wave stages whole 8-row groups");
+  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");
   constexpr int NP = AJ + BJ;
   constexpr int STAGE = (BM + BN) * 128;                 // bytes
-  __shared__ __attribute__((aligned(128))) unsigned char smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
   const char* bptr[BJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int r = wave * (BM / 4) + j * 8 + srow;
+    const int r = wave * (BM / NW) + j * 8 + srow;
     acol[j] = (pslot ^ ((r >> 1) & 7)) * 16;
     const int m = m0 + r;
     ad[j] = decode_row(p, m);
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
   }
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int r = wave * (BN / 4) + j * 8 + srow;
+    const int r = wave * (BN / NW) + j * 8 + srow;
     const int n = min(n0 + r, p.Nc - 1);                  // columns past Nc are computed on a clamped row, never stored
     bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ ((r >> 1) & 7)) * 16;
   }
@@ -84,14 +92,27 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
   const int kpt = p.Ci >> 6;          // K tiles per tap
   const int nk = p.ntaps * kpt;
 
-  // one DMA piece of the tile (pack = tap descriptor, c0b = byte offset of the channel chunk)
-  auto issue_piece = [&](int pack, int c0b, int stage, auto pc_c) __attribute__((always_inline)) {
+  // issue cursor: the tile the next DMA pieces belong to
+  int tap_n = 0, chunk_n = 0;
+  int pack_cur = nk > 0 ? p.tap[0] : 0;
+  int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
+  auto advance = [&]() __attribute__((always_inline)) {
+    if (++chunk_n == kpt) {
+      chunk_n = 0;
+      ++tap_n;
+      pack_cur = pack_next;
+      pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+    }
+  };
+  // one DMA piece of the cursor's tile into ring slot `stage`
+  auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
-    unsigned char* la = smem + stage * STAGE + wave * (BM / 4) * 128;
-    unsigned char* lb = smem + stage * STAGE + BM * 128 + wave * (BN / 4) * 128;
+    const int c0b = chunk_n * 128;
+    unsigned char* la = smem + stage * STAGE + wave * (BM / NW) * 128;
+    unsigned char* lb = smem + stage * STAGE + BM * 128 + wave * (BN / NW) * 128;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
-      const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24;
+      const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
       const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
       const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
       const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
@@ -99,7 +120,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
       dma16(sel_ptr(src, zline, in), la + j * 8 * 128);
     } else {
       constexpr int j = pc - AJ;
-      const int wt = pack >> 16;
+      const int wt = pack_cur >> 16;
       dma16(bptr[j] + (long long)wt * p.Ci * 2 + c0b, lb + j * 8 * 128);
     }
   };
@@ -118,29 +139,32 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
   int goff[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) goff[g] = ((2 * g + lh) ^ xr) * 16;
-  const unsigned char* fragA0 = smem + (wm * 64 + lrow) * 128;
-  const unsigned char* fragB0 = smem + BM * 128 + (wn * 64 + lrow) * 128;
+  const unsigned char* fragA0 = smem + (wm * TM * 32 + lrow) * 128;
+  const unsigned char* fragB0 = smem + BM * 128 + (wn * TN * 32 + lrow) * 128;
 
-  int tap_n = 0, chunk_n = 0;
-  int pack_cur = nk > 0 ? p.tap[0] : 0;
-  int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
-  if (nk > 0) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(pack_cur, 0, 0, pc); });
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of tile kt has landed
-    __syncthreads();                                   // everyone's has; and everyone is done reading stage cur^1
-    const bool more = (kt + 1 < nk) && !(p.debug & 2);   // probe 2: no DMA after the first tile
-    if (more) {
-      if (++chunk_n == kpt) {
-        chunk_n = 0;
-        ++tap_n;
-        pack_cur = pack_next;
-        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
-      }
+  // prologue: tiles 0 .. NST-2
+  int istage = 0;                         // ring slot the cursor's tile goes to
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t) {
+    if (t < nk) {
+      static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(istage, pc); });
+      advance();
+      istage = (istage + 1 == NST) ? 0 : istage + 1;
     }
-    const int c0b = chunk_n * 128;
-    const unsigned char* fa = fragA0 + cur * STAGE;
-    const unsigned char* fb = fragB0 + cur * STAGE;
+  }
+  int cstage = 0;                         // ring slot of the tile being multiplied
+  for (int kt = 0; kt < nk; ++kt) {
+    // my pieces of tile kt have landed; the pieces of one newer tile (NST == 3) may still be in flight
+    if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // everyone's have; and everyone is done reading ring slot istage
+    const bool more = (kt + NST - 1 < nk) && !(p.debug & 2);   // probe 2: no DMA after the prologue
+    const unsigned char* fa = fragA0 + cstage * STAGE;
+    const unsigned char* fb = fragB0 + cstage * STAGE;
+    // all DMA pieces right after the barrier: with the 16x faster MFMA there is no issue cost worth hiding, and the earlier
+    // the loads leave the sooner they land (+2..8 % over spreading them between the MFMA groups; probe 4 = spread)
+    const bool clustered = (p.debug & 4) == 0;
+    if (more && clustered) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(istage, pc); });
     static_for<4>([&](auto g_c) __attribute__((always_inline)) {
       constexpr int g = decltype(g_c)::value;
       bf16x8 a[TM], b[TN];
@@ -148,11 +172,10 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
       for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * 128 + goff[g]);
 #pragma unroll
       for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * 128 + goff[g]);
-      // the next tile's DMA pieces, NP/4 per MFMA group
-      if (more) {
-        constexpr int P0 = g * NP / 4, P1 = (g + 1) * NP / 4;     // NP = 8 or 10: 2,2,2,2 / 2,3,2,3 pieces per group
+      if (more && !clustered) {   // DMA pieces of tile kt + NST - 1, spread over the four MFMA groups
+        constexpr int P0 = g * NP / 4, P1 = (g + 1) * NP / 4;
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
-          issue_piece(pack_cur, c0b, cur ^ 1, std::integral_constant<int, P0 + decltype(q_c)::value>{});
+          issue_piece(istage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
         });
       }
 #pragma unroll
@@ -161,43 +184,79 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GatherGemmP
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     });
+    if (more) {
+      advance();
+      istage = (istage + 1 == NST) ? 0 : istage + 1;
+    }
+    cstage = (cstage + 1 == NST) ? 0 : cstage + 1;
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the stages
 
   if (p.debug & 1) {   // probe 1: no epilogue (one store keeps the accumulators alive)
-    if (acc[0][0][0] + acc[1][1][3] == 123.456f) reinterpret_cast<float*>(p.out)[0] = 1.f;
+    if (acc[0][0][0] + acc[TM - 1][TN - 1][3] == 123.456f) reinterpret_cast<float*>(p.out)[0] = 1.f;
     return;
   }
   if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
-  if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, 2 * STAGE / 4>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
-  else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, 2 * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
+  if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, NST * STAGE / 4>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+  else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, NST * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
 }
 
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
+
+template <int BM, int BN, int WM, int WN, int EPI, int NST>
+static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
+  constexpr int lds = NST * (BM + BN) * 128;
+  auto kern = gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI, NST>;
+  static bool attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_last_error("gather_gemm(bf16): cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+static int gg16_launch(const GatherGemmParams& p, int grid, hipStream_t s) {
+  switch (p.flags) {
+    case 0: return gg16_launch_one<BM, BN, WM, WN, 0, NST>(p, grid, s);
+    case EPI_STATS: return gg16_launch_one<BM, BN, WM, WN, EPI_STATS, NST>(p, grid, s);
+    case EPI_ACCUM: return gg16_launch_one<BM, BN, WM, WN, EPI_ACCUM, NST>(p, grid, s);
+    case EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD, NST>(p, grid, s);
+    default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
+  }
+}
+
+// R3M_BF16_RING=n: use the 8-wave / 3-stage configuration for launches with >= n K tiles. Default 0 = never: measured on
+// ResNet-50 shapes it LOSES 20-30 % to two co-resident 4-wave blocks (one block per CU leaves its prologue and epilogue
+// uncovered, and the 2 x 4 wave layout reads 1.5x the LDS bytes per tile). Kept for experiments.
+static int gg16_ring_min() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_BF16_RING"); v = e ? atoi(e) : 0; }
+  return v;
+}
 
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);
   const double flops = 2.0 * (double)p.M * (double)p.Nc * (double)p.ntaps * p.Ci;
-#define GG16_SWITCH(BM, BN, WM, WN)                                                                                   \
-  switch (p.flags) {                                                                                                   \
-    case 0: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), 0, s, p); break;   \
-    case EPI_STATS: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_STATS>), dim3(grid), dim3(256), 0, s, p); break; \
-    case EPI_ACCUM: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_ACCUM>), dim3(grid), dim3(256), 0, s, p); break; \
-    case EPI_MASKED_ADD: hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI_MASKED_ADD>), dim3(grid), dim3(256), 0, s, p); break; \
-    default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;         \
-  }
+  const int nk = p.ntaps * (p.Ci / 64);
+  const bool ring = gg16_ring_min() > 0 && nk >= gg16_ring_min();
+  int rc;
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    GG16_SWITCH(128, 128, 2, 2)
+    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    GG16_SWITCH(256, 64, 4, 1)
+    rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
-#undef GG16_SWITCH
   prof_end(s);
+  if (rc) return rc;
   return check_launch("gather_gemm_bf16");
 }
 

@@ -89,7 +89,8 @@ __device__ __forceinline__ void gg_stats(const GatherGemmParams& p, f32x16 (&acc
 
 // ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
 // Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
-// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; flag-dependent operand reads are
+// writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; no block barrier is involved, so the
+// waves of a block drain independently (the caller's barrier after the K loop already retired the operand tiles); flag-dependent operand reads are
 // compile-time (EPI) so the plain-store path carries no loads (and no vmcnt waits between stores).
 template <int BM, int BN, int WM, int WN, int EPI, int SMEM_FLOATS, class OT = float>
 __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
@@ -124,7 +125,7 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the slab is private to the wave: its own LDS accesses execute in order
 #pragma unroll
     for (int it = 0; it < 32 / RPI; ++it) {
       const int lr = it * RPI + erow;
@@ -169,7 +170,7 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
         st4t(dst, v);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // the slab is private to the wave: its own LDS accesses execute in order
   }
 }
 
