@@ -412,6 +412,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   };
 
   auto mfma_stage = [&](const unsigned char* st, int dma_stage) __attribute__((always_inline)) {
+    // the next K step's DMA: all pieces right after the barrier (p.interleave = 1: spread between the MFMA groups instead)
+    if (dma_stage >= 0 && !p.interleave) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(dma_stage, pc); });
     static_for<4>([&](auto s_c) __attribute__((always_inline)) {
       constexpr int sidx = decltype(s_c)::value;
       bf16x8 a[TM], b[TN];
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
       for (int t = 0; t < TM; ++t) a[t] = frag(st + fa_off[t], A_ROWB, sidx);
 #pragma unroll
       for (int t = 0; t < TN; ++t) b[t] = frag(st + fb_off[t], B_ROWB, sidx);
-      if (dma_stage >= 0) {
+      if (dma_stage >= 0 && p.interleave) {
         constexpr int P0 = sidx * NP / 4, P1 = (sidx + 1) * NP / 4;
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
           issue_piece(dma_stage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
@@ -482,6 +484,9 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   prof_begin(wide ? KC_WGRAD_WIDE : KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
   p.gx = tilesM * p.tilesN * T;
   {
+    static int il = -1;
+    if (il < 0) { const char* e = getenv("R3M_WG_INTERLEAVE"); il = e ? atoi(e) : 0; }
+    p.interleave = il;
     static int xc = -1;
     if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
     p.xcd = xc;

@@ -89,3 +89,29 @@ def test_oracle_full_step_matches_reference_golden(golden_dir):
     sd = m.convnet.state_dict()
     assert rel_err(sd["bn1.running_var"].numpy(), g["post_bn1.running_var"])[0] < 1e-5
     assert np.abs(sd["bn1.weight"].numpy() - g["post_bn1.weight"]).max() < 4.2e-4
+
+
+def test_bf16_emulation_checker_is_sane():
+    """oracle/bf16_emul.py (the checker of the mixed-precision encoder): it must actually round (differs from the exact
+    float64 graph), stay at bf16 distance from it on a well-conditioned case (ResNet-18, eval-mode BatchNorm), keep weight
+    gradients wide and activation gradients rounded."""
+    from oracle import bf16_emul, resnet_ref
+    torch.manual_seed(3)
+    net = resnet_ref.resnet18().double()
+    net.eval()
+    x = torch.randn(2, 3, 224, 224, dtype=torch.float64)
+
+    def exact(v):
+        z = net.maxpool(net.relu(net.bn1(net.conv1(v))))
+        return net.layer4(net.layer3(net.layer2(net.layer1(z)))).mean((2, 3))
+
+    h_ex = exact(x)
+    h_em = bf16_emul.forward_bf16(net, x)
+    rel = float((h_em - h_ex).norm() / h_ex.norm())
+    assert 1e-4 < rel < 2e-2, rel
+    h_em.sum().backward()
+    g = net.layer1[0].conv1.weight.grad
+    assert g is not None and torch.isfinite(g).all()
+    assert not torch.equal(g, g.to(torch.bfloat16).to(g.dtype))          # weight gradients are NOT rounded to bf16
+    q = bf16_emul._QAct.apply(torch.tensor([1.0 + 2.0 ** -10], dtype=torch.float64, requires_grad=True))
+    assert float(q) == 1.0                                               # 2^-10 is below bf16 resolution at 1.0
