@@ -138,17 +138,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Y
                                                           const float* __restrict__ shift, const T* __restrict__ R,
                                                           const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                           T* __restrict__ Z, long long n4, int c4mask, int relu,
-                                                          unsigned* __restrict__ maskbits) {
-  // grid-stride loop: the stride (gridDim.x * 256) is a multiple of C/4, so the thread's channels and their coefficients
-  // are loop-invariant. n4 is a multiple of 8 when maskbits is used: an 8-lane nibble group is all in or all out.
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                          unsigned* __restrict__ maskbits, int span) {
+  // A block owns `span` consecutive items and walks them 256 at a time; the launcher only picks span > 256 when 256 is a
+  // multiple of C/4, so the thread's channels and their coefficients are loop-invariant (loaded once, and the block's
+  // accesses stay one contiguous range). n4 is a multiple of 8 when maskbits is used: an 8-lane nibble group is all in or out.
+  long long i = (long long)blockIdx.x * span + threadIdx.x;
   if (i >= n4) return;
-  const long long stride = (long long)gridDim.x * 256;
+  const long long end = min((long long)(blockIdx.x + 1) * span, n4);
   const int c = ((int)(i & c4mask)) * 4;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
   f32x4 sc2 = sc, sh2 = sh;
   if (MODE == 2) { sc2 = ld4(scale2 + c); sh2 = ld4(shift2 + c); }
-  for (; i < n4; i += stride) {
+  for (; i < end; i += 256) {
   const f32x4 y = ld4t(Y + i * 4);
   f32x4 z;
 #pragma unroll
@@ -201,18 +202,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const bf16_t* __restr
                                                             const float* __restrict__ shift, const bf16_t* __restrict__ R,
                                                             const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                             bf16_t* __restrict__ Z, long long n8, int c8mask, int relu,
-                                                            unsigned* __restrict__ maskbits) {
-  // grid-stride loop: the stride (gridDim.x * 256) is a multiple of C/8, so a thread keeps ITS 8 channels and loads the
-  // per-channel coefficients once — at 16 B of payload per load the coefficient vectors would otherwise be most of the
+                                                            unsigned* __restrict__ maskbits, int span) {
+  // A block owns `span` consecutive items, 256 at a time: 256 is a multiple of C/8, so a thread keeps ITS 8 channels and loads
+  // the per-channel coefficients once — at 16 B of payload per load the coefficient vectors would otherwise be most of the
   // L1 traffic. n8 is a multiple of 4 when maskbits is used: a 4-lane word group is all in or all out.
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long i = (long long)blockIdx.x * span + threadIdx.x;
   if (i >= n8) return;
-  const long long stride = (long long)gridDim.x * 256;
+  const long long end = min((long long)(blockIdx.x + 1) * span, n8);
   const int c = ((int)(i & c8mask)) * 8;
   const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c);
   f32x8 sc2, sh2;
   if (MODE == 2) { sc2 = ld8f(scale2 + c); sh2 = ld8f(shift2 + c); }
-  for (; i < n8; i += stride) {
+  for (; i < end; i += 256) {
   const f32x8 y = ld8(Y + i * 8);
   f32x8 z;
   FOR8(z, fmaf(y.lo[e], sc.lo[e], sh.lo[e]), fmaf(y.hi[e], sc.hi[e], sh.hi[e]))
@@ -239,19 +240,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const bf16_t* __restr
 
 static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
-// grid for the grid-stride elementwise kernels: about 4 items per thread, and grid * 256 a multiple of the channel-vector
-// count cv (= C/4 or C/8, a power of two) so that a thread meets the same channels at every iteration
-// Items per thread, measured (tools/bn_bench.py): the forward passes are fastest with one item per thread (6.0-6.3 TB/s vs
-// 5.6-5.9 with four); the backward apply pass, which carries six coefficient vectors per thread, gains 15-20 % from four
-// items per thread in bf16 and for C >= 512 in fp32 (coefficient loads amortised). R3M_BN_ITEMS overrides both.
-static inline int stride_safe_grid(long long n_items, int cv, int items) {
+// Items per block of the elementwise passes (span = 256 * items consecutive items per block, walked 256 at a time).
+// More than one item per thread needs 256 % cv == 0 (cv = C/4 or C/8 channel vectors per row) so that the thread's channels
+// are loop-invariant. Measured (tools/bn_bench.py): the forward passes are fastest with one item per thread (6.0-6.3 TB/s
+// against 5.5-5.9 with four); the backward apply pass, which carries six coefficient vectors per thread, gains 15-20 % from
+// four items per thread in bf16, and a few % for C >= 512 in fp32. R3M_BN_ITEMS overrides.
+static inline int bn_span(int cv, int items) {
   static int force = -1;
   if (force < 0) { const char* e = getenv("R3M_BN_ITEMS"); force = e ? atoi(e) : 0; }
   if (force > 0) items = force;
-  int grid = ceil_div(n_items, 256LL * items);
-  const int q = cv > 256 ? cv / 256 : 1;
-  grid = (grid + q - 1) / q * q;
-  return grid < 1 ? 1 : grid;
+  if (cv > 256 || 256 % cv != 0) items = 1;
+  return 256 * items;
 }
 
 int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, const void* Rv, const float* scale2,
@@ -260,19 +259,21 @@ int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, co
   R3M_REQUIRE(!maskbits || (rows * C / 4) % 8 == 0, "bn_act_fwd: bit mask needs rows*C to be a multiple of 32");
   const long long n4 = rows * C / 4;
   const int c4mask = C / 4 - 1;
-  const int grid = stride_safe_grid(n4, C / 4, 1);   // grid * 256 must be a multiple of C/4
+  const int span = bn_span(C / 4, 1);
+  const int grid = ceil_div(n4, span);
   if (dt == DT_BF16 && C >= 8) {
     const bf16_t* Y = static_cast<const bf16_t*>(Yv);
     const bf16_t* R = static_cast<const bf16_t*>(Rv);
     bf16_t* Z = static_cast<bf16_t*>(Zv);
     const long long n8 = rows * C / 8;
-    const int g8 = stride_safe_grid(n8, C / 8, C >= 2048 ? 4 : 1), c8mask = C / 8 - 1;
+    const int span8 = bn_span(C / 8, C >= 2048 ? 4 : 1);
+    const int g8 = ceil_div(n8, span8), c8mask = C / 8 - 1;
     if (R && scale2)
-      hipLaunchKernelGGL((bn_act_fwd16_kernel<2>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<2>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits, span8);
     else if (R)
-      hipLaunchKernelGGL((bn_act_fwd16_kernel<1>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<1>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits, span8);
     else
-      hipLaunchKernelGGL((bn_act_fwd16_kernel<0>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd16_kernel<0>), dim3(g8), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n8, c8mask, relu, maskbits, span8);
     return check_launch("bn_act_fwd16");
   }
   DT_DISPATCH(dt, "bn_act_fwd", {
@@ -280,11 +281,11 @@ int launch_bn_act_fwd(const void* Yv, const float* scale, const float* shift, co
     const T* R = static_cast<const T*>(Rv);
     T* Z = static_cast<T*>(Zv);
     if (R && scale2)
-      hipLaunchKernelGGL((bn_act_fwd_kernel<2, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd_kernel<2, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits, span);
     else if (R)
-      hipLaunchKernelGGL((bn_act_fwd_kernel<1, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd_kernel<1, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits, span);
     else
-      hipLaunchKernelGGL((bn_act_fwd_kernel<0, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits);
+      hipLaunchKernelGGL((bn_act_fwd_kernel<0, T>), dim3(grid), dim3(256), 0, s, Y, scale, shift, R, scale2, shift2, Z, n4, c4mask, relu, maskbits, span);
   });
   return check_launch("bn_act_fwd");
 }
@@ -474,14 +475,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ c1,
                                                             const float* __restrict__ c2, T* __restrict__ dY,
-                                                            long long n4, int c4mask) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                            long long n4, int c4mask, int span) {
+  long long i = (long long)blockIdx.x * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd_kernel
   if (i >= n4) return;
-  const long long stride = (long long)gridDim.x * 256;   // multiple of C/4: channels and coefficients are loop-invariant
+  const long long end = min((long long)(blockIdx.x + 1) * span, n4);
   const int c = ((int)(i & c4mask)) * 4;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
-  for (; i < n4; i += stride) {
+  for (; i < end; i += 256) {
   const f32x4 y = ld4t(Y + i * 4);
   const f32x4 dz = ld4t(dZ + i * 4);
   f32x4 g;
@@ -512,14 +513,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const bf16_t* __res
                                                               const float* __restrict__ shift, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, const float* __restrict__ c1,
                                                               const float* __restrict__ c2, bf16_t* __restrict__ dY, long long n8,
-                                                              int c8mask) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                              int c8mask, int span) {
+  long long i = (long long)blockIdx.x * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd16_kernel
   if (i >= n8) return;
-  const long long stride = (long long)gridDim.x * 256;   // multiple of C/8: the thread's channels (and coefficients) are loop-invariant
+  const long long end = min((long long)(blockIdx.x + 1) * span, n8);
   const int c = ((int)(i & c8mask)) * 8;
   const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c), mu = ld8f(mean + c), is = ld8f(invstd + c);
   const f32x8 k1 = ld8f(c1 + c), k2 = ld8f(c2 + c);
-  for (; i < n8; i += stride) {
+  for (; i < end; i += 256) {
   const f32x8 y = ld8(Y + i * 8);
   const f32x8 dz = ld8(dZ + i * 8);
   f32x8 g;
@@ -542,15 +543,17 @@ int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits
   R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_apply: C=%d must be a power of two >= 4", C);
   if (use_v8(dt, C) && !Zmask) {
     const long long n8 = rows * C / 8;
-    hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(stride_safe_grid(n8, C / 8, 4)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
-                       static_cast<const bf16_t*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<bf16_t*>(dY), n8, C / 8 - 1);
+    const int span8 = bn_span(C / 8, 4);
+    hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(ceil_div(n8, span8)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
+                       static_cast<const bf16_t*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<bf16_t*>(dY), n8, C / 8 - 1, span8);
     return check_launch("bn_bwd_apply16");
   }
   const long long n4 = rows * C / 4;
+  const int span = bn_span(C / 4, C >= 512 ? 4 : 1);
   DT_DISPATCH(dt, "bn_bwd_apply",
-              hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(stride_safe_grid(n4, C / 4, C >= 512 ? 4 : 1)), dim3(256), 0, s, static_cast<const T*>(dZ),
+              hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ceil_div(n4, span)), dim3(256), 0, s, static_cast<const T*>(dZ),
                                  static_cast<const T*>(Zmask), Zbits, static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2,
-                                 static_cast<T*>(dY), n4, C / 4 - 1));
+                                 static_cast<T*>(dY), n4, C / 4 - 1, span));
   return check_launch("bn_bwd_apply");
 }
 

@@ -294,7 +294,8 @@ def test_encoder_bf16_matches_emulation(hip, size):
     exact-to-one-rounding parity statement; test_train_steps_bf16_track_fp32 covers the training trajectory."""
     from oracle import bf16_emul, detgen, resnet_ref
     from r3m_amd import R3M
-    N = 8
+    N = 8 if size != 50 else 4            # the float64 CPU evaluations dominate this test's run time
+    modes = (False, True) if size != 50 else (False,)
     torch.manual_seed(11)
     ref = getattr(resnet_ref, f"resnet{size}")().double()
     x = torch.from_numpy(detgen.frames("frames16", (16, 3, 224, 224)))[:N]
@@ -338,7 +339,7 @@ def test_encoder_bf16_matches_emulation(hip, size):
         assert all(torch.isfinite(v).all() for v in g.values())
         return h.detach().cpu().double(), g
 
-    for training in (False, True):
+    for training in modes:
         h_ex, g_ex = run_ref(exact, training)
         h_em, g_em = run_ref(lambda v: bf16_emul.forward_bf16(ref, v), training)
         h16, g16 = run_hip("bf16", training)

@@ -33,8 +33,8 @@ for i in range(1, 5):
 
 
 def group(k):
-    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<128, 128, 2, 2, \d+>", "gather_gemm 128x128 (all epilogues)", k)
-    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<256, 64, 4, 1, \d+>", "gather_gemm 256x64 (all epilogues)", k)
+    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<128, 128, 2, 2, \d+(, \d+)?>", "gather_gemm 128x128 (all epilogues)", k)
+    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<256, 64, 4, 1, \d+(, \d+)?>", "gather_gemm 256x64 (all epilogues)", k)
     return k
 
 
