@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libr3m_hip.so")
+LIB_PATH = os.environ.get("R3M_HIP_LIB") or os.path.join(_HERE, "lib", "libr3m_hip.so")   # env: A/B builds of the same ABI
 
 _lib = None
 
