@@ -17,6 +17,34 @@ __device__ __forceinline__ void st4t(bf16_t* p, f32x4 v) { *reinterpret_cast<bf1
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// conv outputs are written once and next read a whole tensor later: optional non-temporal stores (R3M_EPI_NT)
+#ifndef R3M_EPI_NT
+#define R3M_EPI_NT 0
+#endif
+typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_out(float* p, f32x4 v) {
+#if R3M_EPI_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st4_out(bf16_t* p, f32x4 v) {
+#if R3M_EPI_NT
+  __builtin_nontemporal_store(__builtin_bit_cast(epi_u32x2, __builtin_convertvector(v, bf16x4)), reinterpret_cast<epi_u32x2*>(p));
+#else
+  *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
+#endif
+}
+__device__ __forceinline__ void st8_out(bf16_t* p, bf16x8 v) {
+#if R3M_EPI_NT
+  __builtin_nontemporal_store(__builtin_bit_cast(epi_u32x4, v), reinterpret_cast<epi_u32x4*>(p));
+#else
+  *reinterpret_cast<bf16x8*>(p) = v;
+#endif
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>) — indices usable as array subscripts without scratch
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
@@ -167,7 +195,7 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
         }
-        st4t(dst, v);
+        st4_out(dst, v);
       }
     }
     __builtin_amdgcn_wave_barrier();   // the slab is private to the wave: its own LDS accesses execute in order
@@ -225,7 +253,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
       const int lr = it * RPI + erow;
       const int row = m0 + wm * TM * 32 + lr;
       if (row < p.M && gcol < p.Nc)
-        *reinterpret_cast<bf16x8*>(outp + row_off(row) + gcol) = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
+        st8_out(outp + row_off(row) + gcol, *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol));
     }
   } else {
     constexpr int CS = CW + 4;           // padded slab row stride (floats)
@@ -270,7 +298,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(outp + eo) = o;
+          st8_out(outp + eo, o);
         }
       }
       __builtin_amdgcn_wave_barrier();
