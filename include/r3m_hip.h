@@ -30,6 +30,7 @@ const char* r3m_last_error(void);
 int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm128x128, gemm128x128 8-wave, gemm256x64, wgrad128} */
 void r3m_profile_enable(int on);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
+int r3m_profile_collect_bytes(double* bytes);     /* algorithmic HBM bytes per class (operands + results once) of the launches of the last collect() */
 int r3m_profile_dump_to(const char* host_path);   /* also write one CSV row per launch at collect(); NULL/"" stops */
 
 /* ---------------- encoder engine -----------------------------------------------------------------------------

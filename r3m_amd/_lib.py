@@ -25,6 +25,7 @@ SIGNATURES = {
     "r3m_debug_occupancy": (c_i, [C.POINTER(c_i)]),
     "r3m_profile_enable": (None, [c_i]),
     "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
+    "r3m_profile_collect_bytes": (c_i, [C.POINTER(c_d)]),
     "r3m_profile_dump_to": (c_i, [C.c_char_p]),
     "r3m_resnet_create": (C.c_void_p, [c_i, c_i]),
     "r3m_resnet_destroy": (None, [C.c_void_p]),

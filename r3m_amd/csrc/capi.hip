@@ -42,7 +42,7 @@ int check_launch(const char* what) {
 }
 
 // ---- per-kernel-class event timing ----
-struct ProfEvent { hipEvent_t a, b; int kclass; double flops; int M, N, K, taps; };
+struct ProfEvent { hipEvent_t a, b; int kclass; double flops, bytes; int M, N, K, taps; };
 static bool g_prof_on = false;
 static std::vector<ProfEvent> g_prof_pool;
 static size_t g_prof_used = 0;
@@ -56,9 +56,13 @@ void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStre
     g_prof_pool.push_back(e);
   }
   ProfEvent& e = g_prof_pool[g_prof_used];
-  e.kclass = kclass; e.flops = flops; e.M = M; e.N = N; e.K = K; e.taps = taps;
+  e.kclass = kclass; e.flops = flops; e.bytes = 0.0; e.M = M; e.N = N; e.K = K; e.taps = taps;
   (void)hipEventRecord(e.a, s);
   g_prof_open = true;
+}
+// algorithmic HBM bytes of the launch opened by prof_begin (operands read once + results written once)
+void prof_bytes(double bytes) {
+  if (g_prof_on && g_prof_open) g_prof_pool[g_prof_used].bytes = bytes;
 }
 void prof_end(hipStream_t s) {
   if (!g_prof_on || !g_prof_open) return;
@@ -133,19 +137,24 @@ int r3m_profile_dump_to(const char* path) {
   if (path && *path) {
     g_prof_dump = fopen(path, "w");
     if (!g_prof_dump) { set_last_error("profile_dump_to: cannot open %s", path); return 1; }
-    fprintf(g_prof_dump, "class,M,N,K,taps,ms,gflop\n");
+    fprintf(g_prof_dump, "class,M,N,K,taps,ms,gflop,alg_mbytes\n");
   }
   return 0;
 }
+static double g_prof_bytes[KC_COUNT];
+int r3m_profile_collect_bytes(double* bytes) {   // algorithmic bytes per class of the launches seen by the LAST collect()
+  for (int k = 0; k < KC_COUNT; ++k) bytes[k] = g_prof_bytes[k];
+  return 0;
+}
 int r3m_profile_collect(double* ms, long long* launches, double* flops) {
-  for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; flops[k] = 0.0; }
+  for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; flops[k] = 0.0; g_prof_bytes[k] = 0.0; }
   for (size_t i = 0; i < g_prof_used; ++i) {
     ProfEvent& e = g_prof_pool[i];
     if (hipEventSynchronize(e.b) != hipSuccess) { set_last_error("profile_collect: event sync failed"); return 1; }
     float t = 0.f;
     if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { set_last_error("profile_collect: elapsed failed"); return 1; }
-    ms[e.kclass] += t; launches[e.kclass] += 1; flops[e.kclass] += e.flops;
-    if (g_prof_dump) fprintf(g_prof_dump, "%d,%d,%d,%d,%d,%.4f,%.3f\n", e.kclass, e.M, e.N, e.K, e.taps, t, e.flops * 1e-9);
+    ms[e.kclass] += t; launches[e.kclass] += 1; flops[e.kclass] += e.flops; g_prof_bytes[e.kclass] += e.bytes;
+    if (g_prof_dump) fprintf(g_prof_dump, "%d,%d,%d,%d,%d,%.4f,%.3f,%.3f\n", e.kclass, e.M, e.N, e.K, e.taps, t, e.flops * 1e-9, e.bytes * 1e-6);
   }
   g_prof_used = 0;
   if (g_prof_dump) fflush(g_prof_dump);

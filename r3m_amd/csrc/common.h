@@ -86,6 +86,7 @@ struct WgradParams {
 
 // ---- launchers (conv.hip) ----
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
+double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem_bytes);
 int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher will use (stats partial rows)
 int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_pick_split(int M, int Co, int Ci, int T);
@@ -133,6 +134,7 @@ int launch_avgpool_bwd(const float* dH, void* dX, int N, int HW, int C, int dt, 
 // ---- optional per-kernel-class HIP-event timing (bench.py roofline; off by default, zero cost when off) ----
 enum { KC_GEMM_WIDE = 0, KC_GEMM_NARROW = 1, KC_WGRAD_WIDE = 2, KC_WGRAD_NARROW = 3, KC_COUNT = 4 };
 void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStream_t s);   // start event (no-op when disabled)
+void prof_bytes(double bytes);                               // algorithmic HBM bytes of the launch just opened (roofline of the HBM-bound path)
 void prof_end(hipStream_t s);                                // records the stop event
 
 }  // namespace r3m

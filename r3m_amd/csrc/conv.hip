@@ -555,6 +555,18 @@ static int gg_use_glds() {
       return 1;                                                                     \
   }
 
+// algorithmic HBM bytes of one gather-GEMM launch: the input tensor once, the weights once, the result once (+ the tensors
+// a read-modify-write epilogue adds: the old result / the residual gradient and its 1-bit mask)
+double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem) {
+  const double in = p.simple_rows ? (double)p.M * p.Ci : (double)p.N * p.Hi * p.Wi * p.Ci;
+  const double out = (double)p.M * p.Nc;
+  double b = elem * (in + out + (double)p.Nc * p.ntaps * p.Ci);
+  if (p.flags & EPI_ACCUM) b += elem * out;
+  if (p.flags & EPI_MASKED_ADD) b += elem * out + out / 8.0;
+  if (p.flags & EPI_MASK_OUT) b += elem * out;
+  return b;
+}
+
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
   if (p.dtype == DT_BF16) {
@@ -615,6 +627,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
 #undef LAUNCH_NARROW
     }
   }
+  prof_bytes(gather_gemm_alg_bytes(p, 4));
   prof_end(s);
   return check_launch("gather_gemm");
 }
@@ -1123,6 +1136,7 @@ int launch_stem_fwd(const float* x_nchw, const float* w147, void* y, float* stat
   p.Hg = 112; p.Wg = 112; p.Ho = 112; p.Wo = 112;
   const double flops = 2.0 * (double)p.M * 64.0 * 147.0;
   prof_begin(KC_GEMM_NARROW, flops, p.M, 64, 147, 1, s);
+  prof_bytes((double)F * 224 * 224 * 3 * 4 + (double)p.M * 64 * (dt == DT_BF16 ? 2 : 4));
   const int ntiles = F * 49;
   const int grid = ntiles < 512 ? ntiles : 512;   // persistent blocks (2 per CU): the 39 KB weight image is staged once per block
   if (dt == DT_BF16) {
@@ -1228,6 +1242,7 @@ int launch_stem_wgrad(const float* x_nchw, const void* dY, float* dw147, float* 
   const int nb = total_rows < STEM_WG_BLOCKS ? total_rows : STEM_WG_BLOCKS;
   const double flops = 2.0 * (double)F * 12544.0 * 64.0 * 147.0;
   prof_begin(KC_WGRAD_NARROW, flops, F * 12544, 64, 147, 1, s);
+  prof_bytes((double)F * 224 * 224 * 3 * 4 + (double)F * 12544 * 64 * (dt == DT_BF16 ? 2 : 4));
   if (dt == DT_BF16)
     hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, x_nchw, static_cast<const bf16_t*>(dY), ws, total_rows);
   else
@@ -1308,6 +1323,7 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
   }
+  prof_bytes(4.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci + (double)splitK * p.Co * T * p.Ci));
   prof_end(s);
   return check_launch("wgrad");
 }

@@ -255,6 +255,7 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
+  prof_bytes(gather_gemm_alg_bytes(p, 2));
   prof_end(s);
   if (rc) return rc;
   return check_launch("gather_gemm_bf16");
@@ -494,6 +495,7 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   const dim3 grid(p.gx * splitK);
   if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+  prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
   prof_end(s);
   return check_launch("wgrad_bf16");
 }
