@@ -245,15 +245,16 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   const double flops = 2.0 * (double)p.M * (double)p.Nc * (double)p.ntaps * p.Ci;
   const int nk = p.ntaps * (p.Ci / 64);
   const bool ring = gg16_ring_min() > 0 && nk >= gg16_ring_min();
+  const bool w8 = gg16_ring_min() < 0;       // experiment: 8 waves, 2 stages (2 blocks/CU = 16 waves/CU)
   int rc;
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
+    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
+    rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : w8 ? gg16_launch<256, 64, 4, 2, 2>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
   prof_bytes(gather_gemm_alg_bytes(p, 2));
   prof_end(s);
