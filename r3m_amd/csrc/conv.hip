@@ -1329,19 +1329,40 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
 }
 
 // dW[i] (+)= sum_s partial[s][i]   — fixed summation order: deterministic gradients
+// dW[i] (+)= sum over split-K slices of partial[s][i], fixed order (deterministic). A block is TX float4 columns x TY slice
+// groups (TX * TY = 256): group g adds slices g, g+TY, ...; the groups are combined through LDS in group order. Small weight
+// tensors (e.g. 64x64x9: 9216 float4, 284 slices) get TY = 16 so that the launch has hundreds of blocks and short load chains
+// instead of 36 blocks walking 284 slices one after the other (that was up to 1 ms per launch).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                            long long n4, long long n, int splitK, int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  f32x4 v = accumulate ? *reinterpret_cast<const f32x4*>(dW + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int sidx = 0; sidx < splitK; ++sidx) v += ldg4(partial + sidx * n + i * 4);
-  *reinterpret_cast<f32x4*>(dW + i * 4) = v;
+                                                            long long n4, long long n, int splitK, int accumulate, int tx_log2) {
+  __shared__ f32x4 red[256];
+  const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
+  const long long i = (long long)blockIdx.x * TX + tx;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int sidx = ty; sidx < splitK; sidx += TY) v += ldg4(partial + sidx * n + i * 4);
+  if (TY == 1) {
+    if (i < n4) {
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dW + i * 4);
+      *reinterpret_cast<f32x4*>(dW + i * 4) = v;
+    }
+    return;
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (ty == 0 && i < n4) {
+    for (int g = 1; g < TY; ++g) v += red[(g << tx_log2) + tx];
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(dW + i * 4);
+    *reinterpret_cast<f32x4*>(dW + i * 4) = v;
+  }
 }
-
 int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s) {
   R3M_REQUIRE(n % 4 == 0, "wgrad_reduce: n=%lld must be a multiple of 4", n);
   const long long n4 = n / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, partial, dW, n4, n, splitK, accumulate);
+  int tx_log2 = 8;                                     // TX = 256, TY = 1
+  while (tx_log2 > 4 && ceil_div(n4, 1 << tx_log2) < 1024 && (256 >> tx_log2) * 2 <= splitK) --tx_log2;   // more slice groups for small tensors
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(n4, 1 << tx_log2)), dim3(256), 0, s, partial, dW, n4, n, splitK, accumulate, tx_log2);
   return check_launch("wgrad_reduce");
 }
 
