@@ -137,6 +137,14 @@ int r3m_bn_act_fwd_dt(const void* y, const float* coef, const void* r, const voi
 int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, const void* y, const float* coef, float* dgamma,
                   float* dbeta, void* dy, void* workspace, size_t workspace_bytes, long long rows, int C, int use_batch_stats,
                   int accumulate, int dtype, r3m_stream_t stream);
+/* Stem tail fused (what the engine runs after conv1): z = relu(bn(y)) is pooled on the fly — the activated tensor and its
+ * gradient, the two largest tensors of the network, are never written. Same arithmetic as r3m_bn_act_fwd + r3m_maxpool_fwd and
+ * r3m_maxpool_bwd + r3m_bn_bwd (mask recomputed from y); workspace = r3m_bn_workspace_bytes(N*Hi*Wi, C). */
+int r3m_bn_relu_maxpool_fwd_dt(const void* y, const float* coef, void* p, unsigned char* argmax, int N, int Hi, int Wi, int C,
+                               int dtype, r3m_stream_t stream);
+int r3m_bn_maxpool_bwd_dt(const void* dp, const unsigned char* argmax, const void* y, const float* coef, float* dgamma, float* dbeta,
+                          void* dy, void* workspace, size_t workspace_bytes, int N, int Hi, int Wi, int C, int use_batch_stats,
+                          int accumulate, int dtype, r3m_stream_t stream);
 int r3m_maxpool_fwd_dt(const void* z, void* p, unsigned char* argmax, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream);
 int r3m_maxpool_bwd_dt(const void* dp, const unsigned char* argmax, void* dz, int N, int Hi, int Wi, int C, int dtype,
                        r3m_stream_t stream);

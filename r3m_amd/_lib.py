@@ -70,6 +70,8 @@ SIGNATURES = {
     "r3m_stem_conv_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_f]),
     "r3m_bn_act_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f, c_i, c_f]),
     "r3m_bn_bwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_bn_relu_maxpool_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_bn_maxpool_bwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_maxpool_fwd_dt": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_maxpool_bwd_dt": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_avgpool_fwd_dt": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),

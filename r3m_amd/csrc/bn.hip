@@ -708,6 +708,206 @@ int launch_maxpool_bwd(const void* dP, const unsigned char* amax, void* dZ, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Stem tail fused: BatchNorm + ReLU + MaxPool (forward) and MaxPool-backward + ReLU/BatchNorm-backward (both passes).
+// The activated stem output Z0 [F,112,112,64] is the largest tensor of the network (4.1 GB fp32 at 1280 frames); the
+// unfused sequence wrote it, re-read it for the pooling, and in backward wrote / twice re-read the equally large dZ0.
+// Fused, Z0 and dZ0 never exist: forward reads Y0 and writes the pooled tensor + argmax; the backward passes read Y0 and
+// gather dZ0 on the fly from the 4x smaller pooled gradient (L2 hits). Arithmetic per element is unchanged: z =
+// relu(fmaf(y, scale, shift)) (rounded to the storage type before the comparison, as the stored Z0 was), first maximum in
+// scan order, dz = sum of the pooled gradients whose argmax points here (rounded to the storage type as the stored dZ0 was).
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ f32x4 round_as(f32x4 v);
+template <>
+__device__ __forceinline__ f32x4 round_as<float>(f32x4 v) { return v; }
+template <>
+__device__ __forceinline__ f32x4 round_as<bf16_t>(f32x4 v) { return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4); }
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, T* __restrict__ P,
+                                                                   unsigned char* __restrict__ amax, long long total, int Hi,
+                                                                   int Wi, int Ho, int Wo, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % C4);
+  long long t = idx / C4;
+  const int px = (int)(t % Wo); t /= Wo;
+  const int py = (int)(t % Ho);
+  const long long n = t / Ho;
+  const f32x4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+  f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  bool first = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int y = py * 2 - 1 + i;
+    if ((unsigned)y >= (unsigned)Hi) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = px * 2 - 1 + j;
+      if ((unsigned)x >= (unsigned)Wi) continue;
+      const f32x4 yv = ld4t(Y + (((n * Hi + y) * Wi + x) * C4 + c4) * 4);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f);
+      v = round_as<T>(v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = i * 3 + j; }
+      first = false;
+    }
+  }
+  st4t(P + idx * 4, best);
+  *reinterpret_cast<uchar4*>(amax + idx * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+}
+
+int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
+                               int Wi, int C, int dt, hipStream_t s) {
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  DT_DISPATCH(dt, "bn_relu_maxpool_fwd",
+              hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(Y),
+                                 scale, shift, static_cast<T*>(P), amax, total, Hi, Wi, Ho, Wo, C / 4));
+  return check_launch("bn_relu_maxpool_fwd");
+}
+
+// gradient w.r.t. the (never stored) pre-pool activation at pixel (n, y, x), channels 4*c4..+3
+template <class T>
+__device__ __forceinline__ f32x4 pool_grad4(const T* __restrict__ dP, const unsigned char* __restrict__ amax, long long n, int y, int x,
+                                            int c4, int Ho, int Wo, int C4) {
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  const int py0 = y >> 1, py1 = (y + 1) >> 1;   // windows py with 2*py-1 <= y <= 2*py+1
+  const int px0 = x >> 1, px1 = (x + 1) >> 1;
+  for (int py = py0; py <= py1; ++py) {
+    if (py >= Ho) continue;
+    const int i = y - (py * 2 - 1);
+    for (int px = px0; px <= px1; ++px) {
+      if (px >= Wo) continue;
+      const int j = x - (px * 2 - 1);
+      const int code = i * 3 + j;
+      const long long o = (((n * Ho + py) * Wo + px) * C4 + c4) * 4;
+      const uchar4 a = *reinterpret_cast<const uchar4*>(amax + o);
+      const f32x4 d = ld4t(dP + o);
+      if (a.x == code) g[0] += d[0];
+      if (a.y == code) g[1] += d[1];
+      if (a.z == code) g[2] += d[2];
+      if (a.w == code) g[3] += d[3];
+    }
+  }
+  return round_as<T>(g);
+}
+
+// pass 1 of BatchNorm backward with dZ gathered through the max-pool: same work split as bn_bwd_reduce_kernel
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                                  const T* __restrict__ Y, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* __restrict__ partials,
+                                                                  long long rows, int C, int cpb4, int rows_per_block, int Hi, int Wi,
+                                                                  int Ho, int Wo) {
+  __shared__ f32x4 red[2][256];
+  const int tcol = threadIdx.x % cpb4, trow = threadIdx.x / cpb4;
+  const int rpp = 256 / cpb4;
+  const int c4 = blockIdx.y * cpb4 + tcol;
+  const int c = c4 * 4;
+  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = r_begin + trow; r < r_end; r += rpp) {
+    const int x = (int)(r % Wi);
+    const long long t = r / Wi;
+    const int yy = (int)(t % Hi);
+    const long long n = t / Hi;
+    const f32x4 y = lds4(Y + r * C + c);
+    const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C / 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
+      s1[e] += g;
+      s2[e] = fmaf(g, (y[e] - mu[e]) * is[e], s2[e]);
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (trow == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s1 += red[0][k * cpb4 + tcol];
+      s2 += red[1][k * cpb4 + tcol];
+    }
+    st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c, s1);
+    st4(partials + ((long long)blockIdx.x * 2 + 1) * C + c, s2);
+  }
+}
+
+// pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                                 const T* __restrict__ Y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                                 const float* __restrict__ c2, T* __restrict__ dY, long long n4, int C4,
+                                                                 int Hi, int Wi, int Ho, int Wo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c4 = (int)(i % C4);
+  long long t = i / C4;
+  const int x = (int)(t % Wi); t /= Wi;
+  const int yy = (int)(t % Hi);
+  const long long n = t / Hi;
+  const int c = c4 * 4;
+  const f32x4 y = lds4(Y + i * 4);
+  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
+  const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
+  const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
+    const float yh = (y[e] - mu[e]) * is[e];
+    o[e] = sc[e] * (g - k1[e] - yh * k2[e]);
+  }
+  sts4(dY + i * 4, o);
+}
+
+// rows of the partial buffer the pooled reduce writes (always the 4-channels-per-thread geometry)
+int bn_bwd_pool_partial_rows(long long rows, int C) {
+  int cpb4, rpb, nblk;
+  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+  return nblk;
+}
+
+int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
+                              hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce_pool: C=%d must be a power of two >= 4", C);
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long long rows = (long long)N * Hi * Wi;
+  int cpb4, rpb, nblk;
+  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+  DT_DISPATCH(dt, "bn_bwd_reduce_pool",
+              hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s,
+                                 static_cast<const T*>(dP), amax, static_cast<const T*>(Y), scale, shift, mean, invstd, partials, rows, C,
+                                 cpb4, rpb, Hi, Wi, Ho, Wo));
+  return check_launch("bn_bwd_reduce_pool");
+}
+
+int launch_bn_bwd_apply_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* c1, const float* c2, void* dY, int N, int Hi, int Wi,
+                             int C, int dt, hipStream_t s) {
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long long n4 = (long long)N * Hi * Wi * (C / 4);
+  DT_DISPATCH(dt, "bn_bwd_apply_pool",
+              hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, static_cast<const T*>(dP), amax,
+                                 static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), n4, C / 4, Hi, Wi, Ho,
+                                 Wo));
+  return check_launch("bn_bwd_apply_pool");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // AdaptiveAvgPool2d(1) + flatten: [N, HW, C] -> [N, C]  and its backward (broadcast of dH / HW)
 // ---------------------------------------------------------------------------------------------------------
 template <class T>

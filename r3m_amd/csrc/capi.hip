@@ -319,6 +319,30 @@ int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const
                float* dbeta, float* dy, void* ws, size_t ws_bytes, long long rows, int C, int use_batch_stats, int accumulate, r3m_stream_t stream) {
   return r3m_bn_bwd_dt(dz, zmask, zbits, y, coef, dgamma, dbeta, dy, ws, ws_bytes, rows, C, use_batch_stats, accumulate, DT_F32, stream);
 }
+// stem tail fused: BatchNorm + ReLU + MaxPool(3,2,1) forward, and its backward (MaxPool gather inside both BN-backward passes)
+int r3m_bn_relu_maxpool_fwd_dt(const void* y, const float* coef, void* p, unsigned char* am, int N, int Hi, int Wi, int C, int dtype,
+                               r3m_stream_t stream) {
+  R3M_REQUIRE(y && coef && p && am, "bn_relu_maxpool_fwd: null argument");
+  if (check_dt(dtype, "bn_relu_maxpool_fwd")) return 1;
+  return launch_bn_relu_maxpool_fwd(y, coef + 2 * C, coef + 3 * C, p, am, N, Hi, Wi, C, dtype, S(stream));
+}
+int r3m_bn_maxpool_bwd_dt(const void* dp, const unsigned char* am, const void* y, const float* coef, float* dgamma, float* dbeta, void* dy,
+                          void* ws, size_t ws_bytes, int N, int Hi, int Wi, int C, int use_batch_stats, int accumulate, int dtype,
+                          r3m_stream_t stream) {
+  R3M_REQUIRE(dp && am && y && coef && dgamma && dbeta && dy && ws, "bn_maxpool_bwd: null argument");
+  if (check_dt(dtype, "bn_maxpool_bwd")) return 1;
+  const long long rows = (long long)N * Hi * Wi;
+  R3M_REQUIRE(ws_bytes >= r3m_bn_workspace_bytes(rows, C), "bn_maxpool_bwd: workspace too small (need %zu)", r3m_bn_workspace_bytes(rows, C));
+  float* partial = static_cast<float*>(ws);
+  double* acc = reinterpret_cast<double*>(static_cast<char*>(ws) + bn_acc_off(rows, C));
+  float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
+  const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
+  if (int e = launch_bn_bwd_reduce_pool(dp, am, y, scale, shift, mean, invstd, partial, N, Hi, Wi, C, dtype, S(stream))) return e;
+  const int prow = bn_bwd_pool_partial_rows(rows, C);
+  if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
+  if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
+  return launch_bn_bwd_apply_pool(dp, am, y, scale, shift, mean, invstd, c12, c12 + C, dy, N, Hi, Wi, C, dtype, S(stream));
+}
 int r3m_maxpool_fwd_dt(const void* z, void* p, unsigned char* am, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream) {
   if (check_dt(dtype, "maxpool_fwd")) return 1;
   return launch_maxpool_fwd(z, p, am, N, Hi, Wi, C, dtype, S(stream));

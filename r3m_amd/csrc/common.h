@@ -126,6 +126,16 @@ int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long coun
 int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dY,
                         long long rows, int C, int dt, hipStream_t s);
+// stem tail fused (Z0 / dZ0 never materialised)
+int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
+                               int Wi, int C, int dt, hipStream_t s);
+int bn_bwd_pool_partial_rows(long long rows, int C);
+int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
+                              hipStream_t s);
+int launch_bn_bwd_apply_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* c1, const float* c2, void* dY, int N, int Hi, int Wi,
+                             int C, int dt, hipStream_t s);
 int launch_maxpool_fwd(const void* Z, void* P, unsigned char* amax, int N, int Hi, int Wi, int C, int dt, hipStream_t s);
 int launch_maxpool_bwd(const void* dP, const unsigned char* amax, void* dZ, int N, int Hi, int Wi, int C, int dt, hipStream_t s);
 int launch_avgpool_fwd(const void* X, float* H, int N, int HW, int C, int dt, hipStream_t s);

@@ -170,7 +170,7 @@ Plan* plan_create(int size, int F, int dtype) {
     c.stats_rows = gather_gemm_grid_m(M, c.Co);
     long long pr = (long long)c.stats_rows * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
-    pr = (long long)bn_bwd_partial_rows(M, c.Co, dtype) * 2 * c.Co;
+    pr = (long long)(i == 0 ? bn_bwd_pool_partial_rows(M, c.Co) : bn_bwd_partial_rows(M, c.Co, dtype)) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
     const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
     if (welems > wmax) wmax = welems;
@@ -182,8 +182,7 @@ Plan* plan_create(int size, int F, int dtype) {
       if (welems * split > wgp_max) wgp_max = welems * split;
     }
   }
-  // stem: Z0 (pre-pool activation), P0 (pooled), argmax bytes
-  P.convs[0].Z_off = take(act(act_elems(P.convs[0])));
+  // stem: P0 (pooled) and the argmax bytes; the pre-pool activation Z0 is never materialised (bn.hip: fused stem tail)
   P.P0_off = take(act(Fll * 56 * 56 * 64));
   P.amax_off = take((Fll * 56 * 56 * 64 + 3) / 4);
   long long cur_in = P.P0_off;
@@ -388,10 +387,9 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
                                 coef(c, L0, 0), coef(c, L0, 1), coef(c, L0, 2), coef(c, L0, 3), 64, s));
     }
   }
-  float* Z0 = arena + L0.Z_off;
-  const long long rows0 = (long long)F * 112 * 112;
-  TRY(launch_bn_act_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), nullptr, nullptr, nullptr, Z0, rows0, 64, 1, nullptr, dt, s));
-  TRY(launch_maxpool_fwd(Z0, arena + P.P0_off, reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, dt, s));
+  // BatchNorm + ReLU + MaxPool in one pass over Y0
+  TRY(launch_bn_relu_maxpool_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), arena + P.P0_off,
+                                 reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, dt, s));
   // ---- residual stages ----
   for (const BlockSpec& B : P.blocks) {
     const float* Xin = arena + B.in_off;
@@ -593,10 +591,21 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
     if (st == 3) {
       // stem: maxpool -> BN+ReLU -> conv1 (no input gradient)
       const ConvSpec& L0 = P.convs[0];
-      float* Gb = Gp(3);
       float* Gc = Gp(4);
-      TRY(launch_maxpool_bwd(Gp(0), reinterpret_cast<const unsigned char*>(arena + P.amax_off), Gb, F, 112, 112, 64, dt, s));
-      TRY(bn_backward(c, L0, Gb, nullptr, Gc));
+      {   // MaxPool backward gathered inside both BatchNorm-backward passes (no dZ0 tensor)
+        const unsigned char* am = reinterpret_cast<const unsigned char*>(arena + P.amax_off);
+        const long long rows = (long long)F * 112 * 112;
+        float* partial = arena + P.partial_off;
+        double* acc = reinterpret_cast<double*>(arena + P.acc_off);
+        TRY(launch_bn_bwd_reduce_pool(Gp(0), am, arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), coef(c, L0, 0), coef(c, L0, 1), partial,
+                                      F, 112, 112, 64, dt, s));
+        const int prow = bn_bwd_pool_partial_rows(rows, 64);
+        TRY(launch_bn_stats_reduce(partial, prow, 64, acc, s));
+        TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, grads + L0.gamma_off, grads + L0.beta_off, coef(c, L0, 4),
+                                        coef(c, L0, 5), accumulate, 64, s));
+        TRY(launch_bn_bwd_apply_pool(Gp(0), am, arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), coef(c, L0, 0), coef(c, L0, 1),
+                                     coef(c, L0, 4), coef(c, L0, 5), Gc, F, 112, 112, 64, dt, s));
+      }
       TRY(join_side());   // the stem wgrad shares the split-K scratch with the side stream's wgrads
       TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, dt, s));
     }
