@@ -589,7 +589,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       const int t = role[0]; role[0] = role[4]; role[4] = t;
     }
     if (st == 3) {
-      // stem: maxpool -> BN+ReLU -> conv1 (no input gradient)
+      // stem: maxpool + BN/ReLU backward (fused) -> conv1 weight gradient (no input gradient)
       const ConvSpec& L0 = P.convs[0];
       float* Gc = Gp(4);
       {   // MaxPool backward gathered inside both BatchNorm-backward passes (no dZ0 tensor)
