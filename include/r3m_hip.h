@@ -111,7 +111,7 @@ int r3m_avgpool_bwd(const float* dh, float* dx, int N, int HW, int C, r3m_stream
 /* ---------------- mixed precision: bf16 activations (BASELINE configs[2], [4]) -------------------------------------
  * The `_dt` variants take `dtype`: R3M_DT_F32 (identical to the plain entry points above) or R3M_DT_BF16. With bf16 every
  * ACTIVATION tensor (x, y, z, r, dy, dz, dx, dp ...) is NHWC bfloat16; what stays fp32: master weights, weight / BatchNorm
- * gradients, BatchNorm statistics partials and coefficients, the stem's normalised input xn, the embedding h / dh, and all
+ * gradients, BatchNorm statistics partials and coefficients, the embedding h / dh, and all
  * accumulation (v_mfma_f32_32x32x16_bf16). This is the counterpart of running the reference's encoder call
  * (r3m/models/models_r3m.py:99, backward at r3m/trainer.py:157) under torch.autocast(bfloat16); the reference itself is
  * fp32 only. Channel counts must be multiples of 64 (every ResNet-18/34/50 layer behind the stem is).
@@ -132,6 +132,15 @@ int r3m_conv2d_wgrad_dt(const void* x, const void* dy, float* dw_ohwi, void* wor
 int r3m_stem_conv_fwd_dt(const float* xn, const float* w_ohwi, void* y, float* stats, int frames, int dtype, r3m_stream_t stream);
 int r3m_stem_conv_wgrad_dt(const float* xn, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int frames,
                            int accumulate, int dtype, r3m_stream_t stream);
+/* The stem on the bf16 MFMA (bf16 plans): r3m_stem_prep_bf16 writes the normalised frames as a padded, channel-interleaved bf16
+ * image xn16[frames][232][704] (r3m_stem_xn16_bytes), from which conv1 forward (y: bf16 [frames,112,112,64], stats as above) and its
+ * weight gradient (dy bf16, dw fp32 [64,7,7,3]) stage their operands by plain contiguous copies. Same call sites as r3m_stem_*. */
+size_t r3m_stem_xn16_bytes(int frames);
+int r3m_stem_prep_bf16(const float* x_nchw, void* xn16, int frames, r3m_stream_t stream);
+int r3m_stem_conv_fwd_bf16(const void* xn16, const float* w_ohwi, void* y, float* stats, int frames, r3m_stream_t stream);
+size_t r3m_stem_conv_wgrad_bf16_workspace_bytes(void);
+int r3m_stem_conv_wgrad_bf16(const void* xn16, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int frames,
+                             int accumulate, r3m_stream_t stream);
 int r3m_bn_act_fwd_dt(const void* y, const float* coef, const void* r, const void* y2, const float* coef2, void* z,
                       long long rows, int C, int relu, unsigned* maskbits, int dtype, r3m_stream_t stream);
 int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, const void* y, const float* coef, float* dgamma,

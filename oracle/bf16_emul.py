@@ -7,9 +7,9 @@ The reference itself is fp32-only; "bf16" is BASELINE.json configs[2]/[4]. What 
 bf16 path computes  fp32-master weights -> bf16 operands -> exact products, wide accumulation -> ONE rounding per stored
 tensor, so that its distance from the fp32 path is the distance of the arithmetic, not of a kernel defect:
 
-  forward   conv output, BatchNorm(+residual)+ReLU output and max-pool output are stored bf16; conv weights are rounded to
-            bf16 for the GEMM; the stem convolution runs on the fp32 frames and fp32 weights (only its output is bf16);
-            BatchNorm statistics, coefficients and the pooled embedding stay wide.
+  forward   the normalised input frames, every conv output, BatchNorm(+residual)+ReLU output and the max-pool output are stored
+            bf16; conv weights (the stem's included) are rounded to bf16 for the GEMM; BatchNorm statistics, coefficients and the
+            pooled embedding stay wide.
   backward  every activation gradient (BatchNorm input gradient, conv input gradient incl. the residual join, max-pool and
             avg-pool input gradient) is stored bf16; weight and BatchNorm-parameter gradients stay wide.
 Known, deliberately ignored differences (O(2^-9 / sqrt(count)) on statistics, one extra rounding on the downsample join):
@@ -71,7 +71,8 @@ def forward_bf16(resnet, x_normalized):
     """resnet: oracle.resnet_ref.ResNet (any float dtype, fc ignored); x_normalized: (x/255 - mean)/std, NCHW.
     Returns the pooled embedding [N, D] (wide)."""
     m = resnet
-    y = _QAct.apply(F.conv2d(x_normalized, m.conv1.weight, None, m.conv1.stride, m.conv1.padding))   # stem: wide operands
+    # stem: the engine keeps the normalised frames as a bf16 image and runs conv1 on the bf16 MFMA like every other conv
+    y = _conv(m.conv1, _round(x_normalized))
     z = _QAct.apply(torch.relu(_bn(m.bn1, y)))
     z = _QAct.apply(F.max_pool2d(z, 3, 2, 1))
     for layer in (m.layer1, m.layer2, m.layer3, m.layer4):

@@ -68,6 +68,11 @@ SIGNATURES = {
     "r3m_conv2d_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 10 + [c_f]),
     "r3m_stem_conv_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),
     "r3m_stem_conv_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_f]),
+    "r3m_stem_xn16_bytes": (c_sz, [c_i]),
+    "r3m_stem_prep_bf16": (c_i, [c_f, c_f, c_i, c_f]),
+    "r3m_stem_conv_fwd_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f]),
+    "r3m_stem_conv_wgrad_bf16_workspace_bytes": (c_sz, []),
+    "r3m_stem_conv_wgrad_bf16": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_f]),
     "r3m_bn_act_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_f, c_i, c_f]),
     "r3m_bn_bwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_ll, c_i, c_i, c_i, c_i, c_f]),
     "r3m_bn_relu_maxpool_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),

@@ -269,6 +269,24 @@ int r3m_stem_conv_wgrad(const float* xn, const float* dy, float* dw_ohwi, void* 
   return r3m_stem_conv_wgrad_dt(xn, dy, dw_ohwi, ws, ws_bytes, frames, accumulate, DT_F32, stream);
 }
 
+// stem on the bf16 MFMA (what bf16 plans run): padded bf16 image of the normalised frames, forward, weight gradient
+size_t r3m_stem_xn16_bytes(int frames) { return stem_xn16_bytes(frames); }
+int r3m_stem_prep_bf16(const float* x, void* xn16, int frames, r3m_stream_t stream) {
+  R3M_REQUIRE(x && xn16, "stem_prep_bf16: null argument");
+  return launch_stem_prep16(x, xn16, frames, S(stream));
+}
+int r3m_stem_conv_fwd_bf16(const void* xn16, const float* w_ohwi, void* y, float* stats, int frames, r3m_stream_t stream) {
+  R3M_REQUIRE(xn16 && w_ohwi && y, "stem_conv_fwd_bf16: null argument");
+  return launch_stem_fwd16(xn16, w_ohwi, y, stats, frames, S(stream));
+}
+size_t r3m_stem_conv_wgrad_bf16_workspace_bytes(void) { return stem_wgrad16_ws_floats() * 4; }
+int r3m_stem_conv_wgrad_bf16(const void* xn16, const void* dy, float* dw_ohwi, void* ws, size_t ws_bytes, int frames, int accumulate,
+                             r3m_stream_t stream) {
+  R3M_REQUIRE(xn16 && dy && dw_ohwi && ws, "stem_conv_wgrad_bf16: null argument");
+  R3M_REQUIRE(ws_bytes >= r3m_stem_conv_wgrad_bf16_workspace_bytes(), "stem_conv_wgrad_bf16: workspace too small");
+  return launch_stem_wgrad16(xn16, dy, dw_ohwi, static_cast<float*>(ws), frames, accumulate, S(stream));
+}
+
 // workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
 static size_t bn_acc_off(long long rows, int C) {
   size_t p = (size_t)bn_bwd_partial_rows(rows, C, DT_F32) * 2 * C * 4;   // the fp32 geometry has the most rows

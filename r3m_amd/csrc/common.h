@@ -107,6 +107,13 @@ int wgrad_bf16_pick_split(int M, int Co, int Ci, int T);
 int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s);
 int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s);
 
+// ---- launchers (stem_bf16.hip): the stem on the bf16 MFMA, from a padded bf16 image of the normalised frames ----
+size_t stem_xn16_bytes(int F);
+int launch_stem_prep16(const float* x_nchw, void* xn16, int F, hipStream_t s);
+int launch_stem_fwd16(const void* xn16, const float* w147, void* y, float* stats, int F, hipStream_t s);
+size_t stem_wgrad16_ws_floats();
+int launch_stem_wgrad16(const void* xn16, const void* dY, float* dw147, float* ws, int F, int accumulate, hipStream_t s);
+
 // ---- launchers (bn.hip) ----
 int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /*[<=64][2][C]*/, hipStream_t s);
 int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, const float* gamma, const float* beta,

@@ -158,7 +158,9 @@ Plan* plan_create(int size, int F, int dtype) {
   const long long Fll = F;
   // arena offsets are in floats whatever the storage type; a bf16 tensor of n elements takes n/2 of them
   auto act = [&](long long n) { return dtype == DT_BF16 ? (n + 1) / 2 : n; };
-  P.col_off = take(Fll * 3 * 224 * 224);   // private copy of the input frames: the stem's weight gradient re-reads them in backward
+  // private normalised copy of the input frames (the stem's weight gradient re-reads it in backward): fp32 channel-interleaved
+  // rows, or for bf16 plans the padded bf16 image of stem_bf16.hip
+  P.col_off = take(dtype == DT_BF16 ? (long long)((stem_xn16_bytes(F) + 3) / 4) : Fll * 3 * 224 * 224);
   long long gmax = 0, partial_max = 0, wmax = 0, wgp_max = 0;
   auto act_elems = [&](const ConvSpec& c) { return Fll * c.Ho * c.Wo * c.Co; };
   for (size_t i = 0; i < P.convs.size(); ++i) {
@@ -175,7 +177,7 @@ Plan* plan_create(int size, int F, int dtype) {
     const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
     if (welems > wmax) wmax = welems;
     if (i == 0) {
-      const long long need = (long long)stem_wgrad_ws_floats() + 64 * 160;
+      const long long need = dtype == DT_BF16 ? (long long)stem_wgrad16_ws_floats() : (long long)stem_wgrad_ws_floats() + 64 * 160;
       if (need > wgp_max) wgp_max = need;
     } else {
       const int split = dtype == DT_BF16 ? wgrad_bf16_pick_split(M, c.Co, c.Ci, c.k * c.k) : wgrad_pick_split(M, c.Co, c.Ci, c.k * c.k);
@@ -372,11 +374,13 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   const ConvSpec& L0 = P.convs[0];
   // normalised, channel-interleaved copy of the frames (0.6 MB/frame): read by the stem forward now and by its weight
   // gradient in backward (the caller's tensor may be gone by then)
-  TRY(launch_stem_prep(x_nchw, arena + P.col_off, F, s));
+  if (dt == DT_BF16) TRY(launch_stem_prep16(x_nchw, arena + P.col_off, F, s));
+  else TRY(launch_stem_prep(x_nchw, arena + P.col_off, F, s));
   {
     float* partial = arena + P.partial_off;
     double* acc = reinterpret_cast<double*>(arena + P.acc_off);
-    TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, dt, s));
+    if (dt == DT_BF16) TRY(launch_stem_fwd16(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, s));
+    else TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, dt, s));
     if (training) {
       TRY(launch_bn_stats_reduce(partial, L0.stats_rows, 64, acc, s));
       TRY(launch_bn_finalize_rows(acc, L0.stats_rows, (long long)F * 12544, params + L0.gamma_off, params + L0.beta_off,
@@ -607,7 +611,8 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
                                      coef(c, L0, 4), coef(c, L0, 5), Gc, F, 112, 112, 64, dt, s));
       }
       TRY(join_side());   // the stem wgrad shares the split-K scratch with the side stream's wgrads
-      TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, dt, s));
+      if (dt == DT_BF16) TRY(launch_stem_wgrad16(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, s));
+      else TRY(launch_stem_wgrad(arena + P.col_off, Gc, grads + L0.w_off, arena + P.wgp_off, F, accumulate, dt, s));
     }
     TRY(join_side());     // a finished stage's gradients are complete on the main stream (all-reduce hook, Adam)
   }

@@ -385,3 +385,42 @@ def test_train_steps_bf16_track_fp32(hip):
     _report(f"bf16 train steps: fp32 {['%.4f' % v for v in losses['fp32']]} bf16 {['%.4f' % v for v in losses['bf16']]}")
     for a, b in zip(losses["fp32"], losses["bf16"]):      # same trajectory, step by step
         assert abs(a - b) <= 5e-2 * abs(a), (losses["fp32"], losses["bf16"])
+
+
+@pytest.mark.parametrize("Fr", [1, 3])
+def test_stem_on_bf16_mfma(hip, Fr):
+    """the bf16 plan's stem: padded bf16 image of the normalised frames -> conv 7x7/2 forward (+ BatchNorm partials) and
+    weight gradient on the bf16 MFMA, vs float64 on the bf16-rounded operands"""
+    x = torch.floor(rnd((Fr, 3, 224, 224), 5, 0.0, 256.0)).clamp(0, 255)
+    w = rnd((64, 3, 7, 7), 6, -0.1, 0.1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    xn = q((x / 255.0 - mean) / std)
+    wr = q(w).double().requires_grad_(True)
+    y_ref = F.conv2d(xn.double(), wr, stride=2, padding=3)
+    dy = q(rnd(tuple(y_ref.shape), 7))
+    y_ref.backward(dy.double())
+    x_raw, wd = x.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    nb = hip.r3m_stem_xn16_bytes(Fr)
+    xn16 = torch.full((nb // 2,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert hip.r3m_stem_prep_bf16(x_raw.data_ptr(), xn16.data_ptr(), Fr, st()) == 0, hip.r3m_last_error()
+    img = xn16.view(Fr, 232, 704).float().cpu()
+    torch.testing.assert_close(img[:, 3:227, 9:681].reshape(Fr, 224, 224, 3), xn.permute(0, 2, 3, 1), rtol=0, atol=0)
+    assert float(img[:, :3].abs().max()) == 0 and float(img[:, 227:].abs().max()) == 0
+    assert float(img[:, :, :9].abs().max()) == 0 and float(img[:, :, 681:].abs().max()) == 0
+    yd = torch.full((Fr, 112, 112, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros((Fr * 49, 2, 64), device=DEV)
+    assert hip.r3m_stem_conv_fwd_bf16(xn16.data_ptr(), wd.data_ptr(), yd.data_ptr(), stats.data_ptr(), Fr, st()) == 0, hip.r3m_last_error()
+    yr = y_ref.detach()
+    e_max, e_l2 = rel_err(nchw(yd.float().cpu()).numpy(), yr.numpy())
+    assert e_max < EPS_BF16 and e_l2 < EPS_BF16 / 2, (e_max, e_l2)
+    np.testing.assert_allclose(stats[:, 0].double().sum(0).cpu().numpy(), yr.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3 * float(yr.abs().max()))
+    np.testing.assert_allclose(stats[:, 1].double().sum(0).cpu().numpy(), (yr * yr).sum((0, 2, 3)).numpy(), rtol=1e-4)
+    dyd = nhwc(dy).to(DEV).to(torch.bfloat16)
+    dwd = torch.full((64, 7, 7, 3), float("nan"), device=DEV)
+    wsb = hip.r3m_stem_conv_wgrad_bf16_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    for acc in (0, 1):
+        assert hip.r3m_stem_conv_wgrad_bf16(xn16.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), ws.data_ptr(), wsb, Fr, acc, st()) == 0, hip.r3m_last_error()
+        e_max, _ = rel_err(dwd.cpu().permute(0, 3, 1, 2).numpy(), (acc + 1) * wr.grad.numpy())
+        assert e_max < 5e-5, (acc, e_max)
