@@ -816,13 +816,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
   if (r_end > rows) r_end = rows;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  for (long long r = r_begin + trow; r < r_end; r += rpp) {
-    const int x = (int)(r % Wi);
-    const long long t = r / Wi;
-    const int yy = (int)(t % Hi);
-    const long long n = t / Hi;
+  // (n, y, x) of the thread's first pixel once; then advanced by rpp pixels per iteration (no divisions in the loop)
+  long long r = r_begin + trow;
+  int x = (int)(r % Wi);
+  long long tq = r / Wi;
+  int yy = (int)(tq % Hi);
+  long long n = tq / Hi;
+  const int dq = rpp / Wi, dr = rpp - dq * Wi;     // rpp = dq * Wi + dr
+  for (; r < r_end; r += rpp) {
     const f32x4 y = lds4(Y + r * C + c);
     const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C / 4);
+    x += dr; yy += dq;
+    if (x >= Wi) { x -= Wi; ++yy; }
+    while (yy >= Hi) { yy -= Hi; ++n; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
@@ -843,34 +849,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
   }
 }
 
-// pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool
+// pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool. One image row (n, y) per block: the pixel /
+// channel-vector split of an item is a shift (C4 is a power of two), so there is no integer division per element.
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
                                                                  const T* __restrict__ Y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ c1,
-                                                                 const float* __restrict__ c2, T* __restrict__ dY, long long n4, int C4,
+                                                                 const float* __restrict__ c2, T* __restrict__ dY, int C4, int c4_log2,
                                                                  int Hi, int Wi, int Ho, int Wo) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const int c4 = (int)(i % C4);
-  long long t = i / C4;
-  const int x = (int)(t % Wi); t /= Wi;
-  const int yy = (int)(t % Hi);
-  const long long n = t / Hi;
+  const int yy = blockIdx.x % Hi;
+  const long long n = blockIdx.x / Hi;
+  const long long row0 = (long long)blockIdx.x * Wi * C4;     // first float4 item of this image row
+  const int items = Wi * C4;
+  // C4 divides 256 (launcher): the thread's channel vector, hence its six coefficient vectors, are loop-invariant
+  const int c4 = threadIdx.x & (C4 - 1);
   const int c = c4 * 4;
-  const f32x4 y = lds4(Y + i * 4);
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
-  const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C4);
-  f32x4 o;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int x = it >> c4_log2;
+    const long long i = row0 + it;
+    const f32x4 y = lds4(Y + i * 4);
+    const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C4);
+    f32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
-    const float yh = (y[e] - mu[e]) * is[e];
-    o[e] = sc[e] * (g - k1[e] - yh * k2[e]);
+    for (int e = 0; e < 4; ++e) {
+      const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
+      const float yh = (y[e] - mu[e]) * is[e];
+      o[e] = sc[e] * (g - k1[e] - yh * k2[e]);
+    }
+    sts4(dY + i * 4, o);
   }
-  sts4(dY + i * 4, o);
 }
 
 // rows of the partial buffer the pooled reduce writes (always the 4-channels-per-thread geometry)
@@ -899,11 +909,13 @@ int launch_bn_bwd_apply_pool(const void* dP, const unsigned char* amax, const vo
                              const float* mean, const float* invstd, const float* c1, const float* c2, void* dY, int N, int Hi, int Wi,
                              int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-  const long long n4 = (long long)N * Hi * Wi * (C / 4);
+  R3M_REQUIRE(is_pow2(C) && C >= 4 && C <= 1024, "bn_bwd_apply_pool: C=%d must be a power of two in [4, 1024]", C);
+  int c4_log2 = 0;
+  while ((1 << c4_log2) < C / 4) ++c4_log2;
   DT_DISPATCH(dt, "bn_bwd_apply_pool",
-              hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, static_cast<const T*>(dP), amax,
-                                 static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), n4, C / 4, Hi, Wi, Ho,
-                                 Wo));
+              hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(N * Hi), dim3(256), 0, s, static_cast<const T*>(dP), amax,
+                                 static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), C / 4, c4_log2, Hi, Wi,
+                                 Ho, Wo));
   return check_launch("bn_bwd_apply_pool");
 }
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);  // DMA instructions per wave per tile (8 rows each)
   static_assert(AJ * 8 * NW == BM && BJ * 8 * NW == BN, "every wave stages whole 8-row groups");
-  static_assert(NST == 2 || NST == 3, "ring of 2 or 3 stages");
+  static_assert(NST >= 1 && NST <= 3, "ring of 1 (single K tile launches only), 2 or 3 stages");
   constexpr int NP = AJ + BJ;
   constexpr int STAGE = (BM + BN) * 128;                 // bytes
   extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -142,8 +142,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   const unsigned char* fragA0 = smem + (wm * TM * 32 + lrow) * 128;
   const unsigned char* fragB0 = smem + BM * 128 + (wn * TN * 32 + lrow) * 128;
 
-  // prologue: tiles 0 .. NST-2
+  // prologue: tiles 0 .. NST-2 (NST == 1: the launch has ONE K tile — 1x1 convs with Cin = 64 — and it is simply loaded; the
+  // block then needs 37 instead of 64 KB of LDS, so three blocks share a CU instead of two)
   int istage = 0;                         // ring slot the cursor's tile goes to
+  if (NST == 1 && nk > 0) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(0, pc); });
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t) {
     if (t < nk) {
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
     if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // everyone's have; and everyone is done reading ring slot istage
-    const bool more = (kt + NST - 1 < nk) && !(p.debug & 2);   // probe 2: no DMA after the prologue
+    const bool more = NST > 1 && (kt + NST - 1 < nk) && !(p.debug & 2);   // probe 2: no DMA after the prologue
     const unsigned char* fa = fragA0 + cstage * STAGE;
     const unsigned char* fb = fragB0 + cstage * STAGE;
     // all DMA pieces right after the barrier: with the 16x faster MFMA there is no issue cost worth hiding, and the earlier
@@ -197,15 +199,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
     return;
   }
   if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
-  if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, NST * STAGE / 4>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
-  else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, NST * STAGE / 4, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
+  // the launcher sizes the dynamic LDS as max(ring, epilogue slabs): with NST == 1 the slabs are the larger
+  constexpr int SMEM_F = (NST == 1 ? 40960 : NST * STAGE) / 4;
+  if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, SMEM_F>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+  else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, SMEM_F, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
 }
 
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NST>
 static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
-  constexpr int lds = NST * (BM + BN) * 128;
+  constexpr int slab = WM * WN * (BM / WM) * (BN / WN + 8) * 2;             // bf16 epilogue slabs (single-pass stores)
+  constexpr int slab32 = WM * WN * 32 * (BN / WN + 4) * 4;                  // fp32 slabs of the read-modify-write epilogues
+  constexpr int tiles = NST * (BM + BN) * 128;
+  constexpr int lds = tiles > slab ? (tiles > slab32 ? tiles : slab32) : (slab > slab32 ? slab : slab32);
   auto kern = gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI, NST>;
   static bool attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
@@ -239,6 +246,13 @@ static int gg16_ring_min() {
   return v;
 }
 
+// R3M_BF16_SINGLE=0 disables the single-stage configuration of one-K-tile launches
+static bool gg16_single() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_BF16_SINGLE"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);
@@ -250,11 +264,13 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
+    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s)
+         : (nk == 1 && gg16_single()) ? gg16_launch<128, 128, 2, 2, 1>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : w8 ? gg16_launch<256, 64, 4, 2, 2>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
+    rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : w8 ? gg16_launch<256, 64, 4, 2, 2>(p, grid, s)
+         : (nk == 1 && gg16_single()) ? gg16_launch<256, 64, 4, 1, 1>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
   prof_bytes(gather_gemm_alg_bytes(p, 2));
   prof_end(s);

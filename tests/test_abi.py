@@ -64,6 +64,25 @@ def test_plan_queries_need_no_gpu():
         L.r3m_resnet_destroy(h)
     assert not L.r3m_resnet_create(101, 4)
     assert b"unsupported" in L.r3m_last_error()
+    assert not L.r3m_resnet_create(50, 0)                      # empty batch: refused at plan time, with a message
+    assert b"F=0" in L.r3m_last_error()
+    assert not L.r3m_resnet_create_dt(50, 4, 7)                # unknown activation dtype
+    assert b"dtype" in L.r3m_last_error()
+
+
+def test_bf16_plan_is_smaller_and_same_parameters():
+    """bf16 plans (BASELINE configs[2], [4]) keep the fp32 parameter / gradient layout and roughly halve the activation arena."""
+    from r3m_amd import _lib
+    L = _lib.lib()
+    for size in (18, 34, 50):
+        h32, h16 = L.r3m_resnet_create_dt(size, 16, 0), L.r3m_resnet_create_dt(size, 16, 1)
+        assert h32 and h16 and L.r3m_resnet_dtype(h32) == 0 and L.r3m_resnet_dtype(h16) == 1
+        assert L.r3m_resnet_num_params(h32) == L.r3m_resnet_num_params(h16)
+        assert L.r3m_resnet_num_tensors(h32) == L.r3m_resnet_num_tensors(h16)
+        a32, a16 = L.r3m_resnet_arena_bytes(h32), L.r3m_resnet_arena_bytes(h16)
+        assert 0.4 * a32 < a16 < 0.75 * a32, (size, a32, a16)
+        L.r3m_resnet_destroy(h32)
+        L.r3m_resnet_destroy(h16)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
