@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--encoder-only-frames", type=int, default=0,
                     help="> 0: the literal reading of 'bs=256': F frames through encoder forward + backward of sum|h| + Adam, no clip "
                          "structure / TCN loss (SURVEY.md §8(d) continuity point); the headline stays the 256-clip step")
+    ap.add_argument("--prewarm-seconds", type=float, default=5.0,
+                    help="untimed steps run BEFORE the --warmup steps until this much wall time has passed: an idle MI355X needs "
+                         "seconds of sustained load to reach its clocks (measured: the same build reads 362-371 ms/step right after an "
+                         "idle period with 2 warm-up steps and 348 ms with 12; 119.8 vs 105.6 ms in bf16). 0 disables.")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket the conv GEMM launches with HIP events (diagnostic: "
                                                                      "measures what the live roofline timing costs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,6 +163,20 @@ def main():
         trainer = _EncTrainer()
         get_frames = lambda: xe
 
+    prewarm_steps = 0
+    if args.prewarm_seconds > 0:                        # device warm-up (clock ramp), outside both the W warm-up and the timed K steps
+        t_pw = time.perf_counter()
+        while True:
+            go = time.perf_counter() - t_pw < args.prewarm_seconds
+            if world > 1:                               # every rank must run the same number of steps (collectives inside)
+                flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go = bool(flag.item())
+            if not go:
+                break
+            trainer.update(net, (get_frames(), langs), 0)
+            torch.cuda.synchronize()
+            prewarm_steps += 1
     for i in range(args.warmup):
         trainer.update(net, (get_frames(), langs), i)
     L.r3m_profile_enable(0 if args.no_kernel_timing else 1)
@@ -206,6 +224,7 @@ def main():
             "metric": "encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU" if args.size == 50 and B == 256 else
                       f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2 bs={B}/GPU",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_steps": prewarm_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{(4 if args.size == 34 else 2) if bf16 else (3 if world > 1 else 1)}]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), "
