@@ -10,10 +10,14 @@
 //       forward conv (taps = kh,kw; input stride = conv stride), dgrad (taps flipped; stride-2 dgrad is run as
 //       4 output-parity classes so no MFMA work is spent on structural zeros), Linear (1 tap).
 //       Epilogues: raw store (+ BatchNorm sum / sum-of-squares partials), accumulate, masked residual-gradient add,
-//       bias (+ReLU), ReLU-mask.  Two staging schemes:
-//         gather_gemm_glds_kernel (128x128 tiles): global -> LDS directly (global_load_lds_dwordx4), XOR-swizzled tiles
-//         gather_gemm_kernel      (256x64 tiles, fallback): global -> VGPR -> LDS, 36-float padded rows
-//   * wgrad_kernel : dW[co, tap, ci] = sum_m dY[m, co] * in[pix(m) + off(tap), ci]   (split-K over m)
+//       bias (+ReLU), ReLU-mask.  Kernels (128x128 tiles, or 256x64 for 64-channel outputs):
+//         gather_gemm_glds2_kernel : the production kernel. global -> LDS directly (global_load_lds_dwordx4), XOR-swizzled 128-byte
+//                                    rows, low-VALU K loop (pointer arrays, two K tiles per iteration), DMA pieces issued between MFMAs
+//         gather_gemm_glds_kernel  : generic direct-to-LDS variant (odd Cin/32; timing probes)
+//         gather_gemm_kernel       : global -> VGPR -> LDS fallback, 36-float padded rows (R3M_GG_GLDS=0)
+//   * wgrad_glds_kernel / wgrad_kernel : dW[co, tap, ci] = sum_m dY[m, co] * in[pix(m) + off(tap), ci]   (split-K over m, XCD-aware order)
+//   * stem_prep / stem_fwd / stem_wgrad : conv1 7x7/2 straight from the frames (no im2col in HBM); legacy im2col route kept in the C ABI
+//   (bf16 plans run conv_bf16.hip / stem_bf16.hip instead.)
 //
 // All staging is branch-free: taps that fall outside the image and rows past the end read a valid dummy address (a
 // zero line / a clamped pixel) instead of being skipped, so the loader is straight-line code the compiler can interleave
