@@ -203,6 +203,11 @@ int r3m_loss_finalize(void* workspace, size_t workspace_bytes, int B, int have_l
  * one pass over the flat buffers; step counts from 1; grad_scale multiplies g on the fly (1/world_size for SUM all-reduce) */
 int r3m_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1,
                   double beta2, double eps, long long step, float grad_scale, r3m_stream_t stream);
+/* torch.optim.SGD on the same flat buffers (momentum / dampening / weight_decay / nesterov as torch defines them; momentum_buf may
+ * be NULL when momentum == 0; step counts from 1 and selects the buffer initialisation). The reference trains with Adam only
+ * (models_r3m.py:76); BASELINE.json's north_star names "the SGD/Adam step". */
+int r3m_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, double lr, double momentum, double dampening,
+                 double weight_decay, int nesterov, long long step, float grad_scale, r3m_stream_t stream);
 
 #ifdef __cplusplus
 }

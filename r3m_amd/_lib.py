@@ -92,6 +92,7 @@ SIGNATURES = {
     "r3m_loss_lang_infonce": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_fl, c_f]),
     "r3m_loss_finalize": (c_i, [c_f, c_sz, c_i, c_i, c_f, c_fl, c_fl, c_fl, c_fl, c_f]),
     "r3m_adam_step": (c_i, [c_f, c_f, c_f, c_f, c_ll, c_d, c_d, c_d, c_d, c_ll, c_fl, c_f]),
+    "r3m_sgd_step": (c_i, [c_f, c_f, c_f, c_ll, c_d, c_d, c_d, c_d, c_i, c_ll, c_fl, c_f]),
 }
 
 

@@ -106,6 +106,8 @@ int launch_loss_finalize(float* ws, int B, int have_lang, float* metrics, float 
                          hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                 long long step, float grad_scale, hipStream_t s);
+int launch_sgd(float* p, const float* g, float* momentum_buf, long long n, double lr, double momentum, double dampening,
+               double weight_decay, int nesterov, long long step, float grad_scale, hipStream_t s);
 // augment.hip
 int launch_crop_resize(const void* in, int in_is_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,
                        int Wo, int frames_per_box, hipStream_t s);
@@ -431,6 +433,12 @@ int r3m_loss_finalize(void* ws, size_t ws_bytes, int B, int have_lang, float* me
 int r3m_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
                   long long step, float grad_scale, r3m_stream_t stream) {
   return launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
+}
+
+int r3m_sgd_step(float* p, const float* g, float* momentum_buf, long long n, double lr, double momentum, double dampening,
+                 double weight_decay, int nesterov, long long step, float grad_scale, r3m_stream_t stream) {
+  R3M_REQUIRE(p && g, "sgd_step: null argument");
+  return launch_sgd(p, g, momentum_buf, n, lr, momentum, dampening, weight_decay, nesterov, step, grad_scale, S(stream));
 }
 
 }  // extern "C"

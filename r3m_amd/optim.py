@@ -65,3 +65,43 @@ class FusedAdam(torch.optim.Optimizer):
                 self._v[i] = sd["exp_avg_sq"][i].to(dev)
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD semantics (momentum, dampening, weight_decay, nesterov) as one HIP kernel per flat buffer. The reference
+    only ever builds Adam (models_r3m.py:76); this is the plain alternative on the same owners protocol."""
+
+    def __init__(self, owners, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        self.owners = list(owners)
+        params = [p for o in self.owners for p in o.parameters()]
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
+        self._step = 0
+        self._buf = [None] * len(self.owners)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=True):
+        for o in self.owners:
+            o.mark_grads_stale()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FusedSGD.step(closure) is not supported")
+        g0 = self.param_groups[0]
+        self._step += 1
+        L = _lib.lib()
+        for i, o in enumerate(self.owners):
+            p = o.flat_params()
+            if not p.is_cuda:
+                raise RuntimeError("r3m_amd.FusedSGD: parameters must live on the GPU (HIP kernel, no CPU fallback)")
+            if not getattr(o, "has_grads", lambda: True)():
+                continue
+            g = o.flat_grads()
+            if g0["momentum"] != 0 and (self._buf[i] is None or self._buf[i].device != p.device or self._buf[i].numel() != p.numel()):
+                self._buf[i] = torch.zeros_like(p)
+            buf_ptr = None if self._buf[i] is None else self._buf[i].data_ptr()
+            _lib.check(L.r3m_sgd_step(p.data_ptr(), g.data_ptr(), buf_ptr, p.numel(), float(g0["lr"]), float(g0["momentum"]),
+                                      float(g0["dampening"]), float(g0["weight_decay"]), int(bool(g0["nesterov"])), self._step,
+                                      float(self.grad_scale), _lib.stream_ptr()), "sgd_step")

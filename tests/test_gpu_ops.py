@@ -371,3 +371,29 @@ def test_stem_tail_fused_equals_unfused(hip, N, H, C, dt):
     # the parameter gradients are sums in a different (but fixed) order between the two reduce kernels
     assert rel_err(dg1.cpu().numpy(), dg0.cpu().numpy())[0] < 1e-5 and rel_err(db1.cpu().numpy(), db0.cpu().numpy())[0] < 1e-5
     assert rel_err(dy1.float().cpu().numpy(), dy0.float().cpu().numpy())[0] < (1e-5 if dt == 0 else 2.0 ** -7)
+
+
+@pytest.mark.parametrize("cfg", [dict(momentum=0.0), dict(momentum=0.9), dict(momentum=0.9, dampening=0.1, weight_decay=1e-2),
+                                 dict(momentum=0.9, nesterov=True, weight_decay=1e-3)], ids=["plain", "momentum", "damp_wd", "nesterov"])
+def test_sgd_matches_torch(hip, cfg):
+    """the plain optimizer of north_star's 'SGD/Adam step': 3 steps vs torch.optim.SGD on the same flat buffer"""
+    n = 4096 + 64
+    p0 = rnd((n,), 81)
+    grads = [rnd((n,), 82 + i, -0.01, 0.01) * (10.0 ** (i - 1)) for i in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=1e-2, **cfg)
+    pd = p0.to(DEV)
+    buf = torch.full((n,), float("nan"), device=DEV)          # must be initialised by step 1, not read
+    for i, g in enumerate(grads):
+        pr.grad = g.clone()
+        opt.step()
+        gd = g.to(DEV)
+        rc = hip.r3m_sgd_step(pd.data_ptr(), gd.data_ptr(), buf.data_ptr() if cfg.get("momentum", 0.0) else None, n, 1e-2,
+                              cfg.get("momentum", 0.0), cfg.get("dampening", 0.0), cfg.get("weight_decay", 0.0),
+                              1 if cfg.get("nesterov") else 0, i + 1, 1.0, st())
+        assert rc == 0, hip.r3m_last_error()
+        torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-9)
+    if cfg.get("momentum", 0.0):
+        ref_buf = opt.state[pr]["momentum_buffer"]     # fp32 round-off level of the buffer's scale (fma contraction differs)
+        torch.testing.assert_close(buf.cpu(), ref_buf, rtol=1e-6, atol=2e-7 * float(ref_buf.abs().max()))
+    assert hip.r3m_sgd_step(pd.data_ptr(), gd.data_ptr(), None, n, 1e-2, 0.9, 0.0, 0.0, 0, 1, 1.0, st()) != 0   # momentum without a buffer
