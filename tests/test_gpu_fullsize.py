@@ -89,3 +89,69 @@ def test_headline_size_properties(hip, precision):
     assert num / den <= (1e-4 if precision == "fp32" else 1e-1), f"{precision}: backward linearity {num / den}"
     del m, x, h
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("l2dist", [True, False])
+def test_headline_size_objective_vs_oracle(hip, l2dist):
+    """The whole objective (LP + TCN + language InfoNCE through the batched reward head) at the headline size B = 256 clips,
+    D = 2048 against the CPU oracle, which finishes this in seconds and so IS the checker here (same permutations, same
+    reward-head weights). Scores and metrics are gated at 1e-5 as at the golden size. The gradient w.r.t. the embeddings is a
+    small difference of large InfoNCE contributions through a K = 4864 fp32 GEMM chain: the oracle's own fp32 evaluation sits
+    up to 2e-3 from its float64 evaluation depending on the weights, so — as for the encoder gradients — the gate is against
+    float64 at <= 4x the fp32 oracle's error (floor 1e-4), per clip, with an allowance for ReLU-kink flips (see below)."""
+    from oracle import r3m_ref
+    from r3m_amd import ops
+    from r3m_amd.models_language import LanguageReward
+    B, D = 256, 2048
+    g = torch.Generator().manual_seed(21)
+    alle_c = torch.rand((B, 5, D), generator=g) * 1.5                      # non-negative like avg-pooled ReLU features
+    feats = (torch.randn((B, 768), generator=g) * 0.3)
+    mask = torch.ones(B)
+    mask[::7] = 0.0                                                        # clips without language
+    lang_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(9)])
+    tcn_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(6)])
+    ref = r3m_ref.R3MRef(size=50, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0, l2dist=l2dist)
+    sd32 = {k: v.clone() for k, v in ref.lang_rew.state_dict().items()}
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        ref.lang_rew.to(dt)
+        a_ref = alle_c.to(dt).clone().requires_grad_(True)
+        fl, met, scores_ref = r3m_ref.r3m_loss_ref(ref, a_ref, tcn_perm=tcn_perm, lang_feats=feats.to(dt), lang_mask=mask.to(dt),
+                                                   lang_perm=lang_perm)
+        ref.zero_grad()
+        fl.backward()
+        res[dt] = (a_ref.grad.double().clone(), {k: float(p.grad.double().norm()) for k, p in ref.lang_rew.named_parameters()}, met,
+                   scores_ref.detach().double().clone())
+    g32, n32, met32, sc32 = res[torch.float32]
+    g64, n64, met64, sc64 = res[torch.float64]
+
+    rew = LanguageReward(None, D, 1024, 768)
+    rew.load_state_dict(sd32)
+    rew = rew.to(DEV)
+    alle = alle_c.to(DEV).requires_grad_(True)
+    scores = rew.batched_scores(alle, feats.to(DEV), lang_perm.to(torch.int32).to(DEV))
+    assert rel_err(scores.detach().cpu().numpy(), sc64.numpy())[0] < 1e-5
+    full, m = ops.r3m_loss(alle, tcn_perm.to(torch.int32).to(DEV), 1e-5, 1e-5, 1.0, l2dist=l2dist, scores=scores, mask=mask.to(DEV),
+                           langweight=1.0)
+    got = m.cpu().numpy()
+    for k, v in met64.items():
+        assert abs(got[ops.METRIC_SLOTS[k]] - v) <= 1e-5 * max(1.0, abs(v)), (k, got[ops.METRIC_SLOTS[k]], v)
+    rew.mark_grads_stale()
+    full.backward()
+    gh = alle.grad.cpu().double()
+    mx = float(g64.abs().max())
+    e_cpu = float((g32 - g64).abs().max()) / mx
+    per_clip = (gh - g64).abs().amax(dim=(1, 2)) / mx                     # worst element of every clip
+    gate = max(4.0 * e_cpu, 1e-4)
+    n_out = int((per_clip > gate).sum())
+    print(f"B=256 D=2048 l2dist={l2dist}: d loss/d alle vs float64: hip median {float(per_clip.median()):.3e} max {float(per_clip.max()):.3e}, "
+          f"{n_out} of {B} clips above {gate:.1e}; oracle-fp32 {e_cpu:.3e}  (max|g| {mx:.3e})")
+    # The reward head has 15 x 256 x 4096 ReLU units; a handful sit within fp32 round-off of their kink, where HIP (sequential fp32
+    # accumulation over K = 4864) and float64 can land on different sides: the gradient of THAT row then changes by the unit's
+    # share (a few %). Measured: 3 of 256 clips at 4e-3..8e-3 of the gradient range, every other clip at 1e-6 (tools/experiments/
+    # debug_lang.py). So: at least 97 % of the clips inside the gate, nobody beyond 5e-2, and the l2 error of the whole tensor small.
+    assert n_out <= 0.03 * B and float(per_clip.max()) <= 5e-2
+    assert float((gh - g64).norm() / g64.norm()) <= 2e-3
+    for k, p in rew.named_parameters():
+        hip_n = float(p.grad.double().norm())
+        assert abs(hip_n - n64[k]) <= max(4.0 * abs(n32[k] - n64[k]), 5e-4 * n64[k], 1e-7), (k, hip_n, n32[k], n64[k])
