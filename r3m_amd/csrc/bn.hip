@@ -723,21 +723,74 @@ __device__ __forceinline__ f32x4 round_as<float>(f32x4 v) { return v; }
 template <>
 __device__ __forceinline__ f32x4 round_as<bf16_t>(f32x4 v) { return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4); }
 
+// Channel vectors per thread: 4 channels (one f32x4) for fp32, 8 channels (two f32x4, one 16-byte load) for bf16 — the bf16
+// tensors are half the bytes, so the 4-wide kernels were instruction-bound there (measured 4.1 / 2.5 / 3.6 TB/s against
+// 7.2 / 5.4 / 5.5 TB/s for fp32).
+template <class T>
+struct PoolVec { static constexpr int V4 = 1; };
+template <>
+struct PoolVec<bf16_t> { static constexpr int V4 = 2; };
+
+template <int V4, class T>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, f32x4 (&q)[V4]) {   // cached: the gathered, re-read operands
+  if constexpr (V4 == 1) {
+    q[0] = ld4t(p);
+  } else {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { q[0][e] = (float)v[e]; q[1][e] = (float)v[4 + e]; }
+  }
+}
+template <int V4, class T>
+__device__ __forceinline__ void ldv_stream(const T* __restrict__ p, f32x4 (&q)[V4]) {   // read once
+  if constexpr (V4 == 1) {
+    q[0] = lds4(p);
+  } else {
+    const f32x8 v = ld8(p);
+    q[0] = v.lo; q[1] = v.hi;
+  }
+}
+template <int V4, class T>
+__device__ __forceinline__ void stv(T* __restrict__ p, const f32x4 (&q)[V4], bool stream) {
+  if constexpr (V4 == 1) {
+    if (stream) sts4(p, q[0]); else st4t(p, q[0]);
+  } else {
+    if (stream) { f32x8 v; v.lo = q[0]; v.hi = q[1]; st8(p, v); }
+    else {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)q[0][e]; o[4 + e] = (bf16_t)q[1][e]; }
+      *reinterpret_cast<bf16x8*>(p) = o;
+    }
+  }
+}
+template <int V4>
+__device__ __forceinline__ void ld_codes(const unsigned char* __restrict__ p, unsigned (&a)[V4]) {   // 4 argmax codes per word
+  if constexpr (V4 == 1) a[0] = *reinterpret_cast<const unsigned*>(p);
+  else { const uint2 v = *reinterpret_cast<const uint2*>(p); a[0] = v.x; a[1] = v.y; }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ Y, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, T* __restrict__ P,
                                                                    unsigned char* __restrict__ amax, long long total, int Hi,
-                                                                   int Wi, int Ho, int Wo, int C4) {
+                                                                   int Wi, int Ho, int Wo, int CV) {
+  constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int c4 = (int)(idx % C4);
-  long long t = idx / C4;
+  const int cv = (int)(idx % CV);
+  long long t = idx / CV;
   const int px = (int)(t % Wo); t /= Wo;
   const int py = (int)(t % Ho);
   const long long n = t / Ho;
-  const f32x4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
-  f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  int bi[4] = {0, 0, 0, 0};
+  f32x4 sc[V4], sh[V4], best[V4];
+  unsigned bi[V4];
+#pragma unroll
+  for (int k = 0; k < V4; ++k) {
+    sc[k] = ld4(scale + cv * V + 4 * k); sh[k] = ld4(shift + cv * V + 4 * k);
+    best[k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bi[k] = 0u;
+  }
   bool first = true;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -747,36 +800,46 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
     for (int j = 0; j < 3; ++j) {
       const int x = px * 2 - 1 + j;
       if ((unsigned)x >= (unsigned)Wi) continue;
-      const f32x4 yv = ld4t(Y + (((n * Hi + y) * Wi + x) * C4 + c4) * 4);
-      f32x4 v;
+      f32x4 yv[V4];
+      ldv<V4>(Y + (((n * Hi + y) * Wi + x) * CV + cv) * V, yv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f);
-      v = round_as<T>(v);
+      for (int k = 0; k < V4; ++k) {
+        f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = i * 3 + j; }
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(yv[k][e], sc[k][e], sh[k][e]), 0.f);
+        v = round_as<T>(v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (first || v[e] > best[k][e]) { best[k][e] = v[e]; bi[k] = (bi[k] & ~(0xffu << (8 * e))) | ((unsigned)(i * 3 + j) << (8 * e)); }
+      }
       first = false;
     }
   }
-  st4t(P + idx * 4, best);
-  *reinterpret_cast<uchar4*>(amax + idx * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+  stv<V4>(P + idx * V, best, false);
+  if constexpr (V4 == 1) *reinterpret_cast<unsigned*>(amax + idx * V) = bi[0];
+  else *reinterpret_cast<uint2*>(amax + idx * V) = make_uint2(bi[0], bi[1]);
 }
 
 int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
                                int Wi, int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-  const long long total = (long long)N * Ho * Wo * (C / 4);
-  DT_DISPATCH(dt, "bn_relu_maxpool_fwd",
-              hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(Y),
-                                 scale, shift, static_cast<T*>(P), amax, total, Hi, Wi, Ho, Wo, C / 4));
+  R3M_REQUIRE(C % 8 == 0, "bn_relu_maxpool_fwd: C=%d must be a multiple of 8", C);
+  DT_DISPATCH(dt, "bn_relu_maxpool_fwd", {
+    constexpr int V = 4 * PoolVec<T>::V4;
+    const long long total = (long long)N * Ho * Wo * (C / V);
+    hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const T*>(Y), scale,
+                       shift, static_cast<T*>(P), amax, total, Hi, Wi, Ho, Wo, C / V);
+  });
   return check_launch("bn_relu_maxpool_fwd");
 }
 
-// gradient w.r.t. the (never stored) pre-pool activation at pixel (n, y, x), channels 4*c4..+3
+// gradient w.r.t. the (never stored) pre-pool activation at pixel (n, y, x), channel vector cv
 template <class T>
-__device__ __forceinline__ f32x4 pool_grad4(const T* __restrict__ dP, const unsigned char* __restrict__ amax, long long n, int y, int x,
-                                            int c4, int Ho, int Wo, int C4) {
-  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void pool_gradv(const T* __restrict__ dP, const unsigned char* __restrict__ amax, long long n, int y, int x,
+                                           int cv, int Ho, int Wo, int CV, f32x4 (&g)[PoolVec<T>::V4]) {
+  constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
+#pragma unroll
+  for (int k = 0; k < V4; ++k) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int py0 = y >> 1, py1 = (y + 1) >> 1;   // windows py with 2*py-1 <= y <= 2*py+1
   const int px0 = x >> 1, px1 = (x + 1) >> 1;
   for (int py = py0; py <= py1; ++py) {
@@ -785,17 +848,21 @@ __device__ __forceinline__ f32x4 pool_grad4(const T* __restrict__ dP, const unsi
     for (int px = px0; px <= px1; ++px) {
       if (px >= Wo) continue;
       const int j = x - (px * 2 - 1);
-      const int code = i * 3 + j;
-      const long long o = (((n * Ho + py) * Wo + px) * C4 + c4) * 4;
-      const uchar4 a = *reinterpret_cast<const uchar4*>(amax + o);
-      const f32x4 d = ld4t(dP + o);
-      if (a.x == code) g[0] += d[0];
-      if (a.y == code) g[1] += d[1];
-      if (a.z == code) g[2] += d[2];
-      if (a.w == code) g[3] += d[3];
+      const unsigned code = (unsigned)(i * 3 + j);
+      const long long o = (((n * Ho + py) * Wo + px) * CV + cv) * V;
+      unsigned a[V4];
+      f32x4 d[V4];
+      ld_codes<V4>(amax + o, a);
+      ldv<V4>(dP + o, d);
+#pragma unroll
+      for (int k = 0; k < V4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (((a[k] >> (8 * e)) & 0xffu) == code) g[k][e] += d[k][e];
     }
   }
-  return round_as<T>(g);
+#pragma unroll
+  for (int k = 0; k < V4; ++k) g[k] = round_as<T>(g[k]);
 }
 
 // pass 1 of BatchNorm backward with dZ gathered through the max-pool: same work split as bn_bwd_reduce_kernel
@@ -804,18 +871,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
                                                                   const T* __restrict__ Y, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ invstd, float* __restrict__ partials,
-                                                                  long long rows, int C, int cpb4, int rows_per_block, int Hi, int Wi,
+                                                                  long long rows, int C, int cpb, int rows_per_block, int Hi, int Wi,
                                                                   int Ho, int Wo) {
-  __shared__ f32x4 red[2][256];
-  const int tcol = threadIdx.x % cpb4, trow = threadIdx.x / cpb4;
-  const int rpp = 256 / cpb4;
-  const int c4 = blockIdx.y * cpb4 + tcol;
-  const int c = c4 * 4;
+  constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
+  __shared__ f32x4 red[2][V4][256];
+  const int tcol = threadIdx.x % cpb, trow = threadIdx.x / cpb;
+  const int rpp = 256 / cpb;
+  const int cv = blockIdx.y * cpb + tcol;
+  const int c = cv * V;
   const long long r_begin = (long long)blockIdx.x * rows_per_block;
   long long r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
-  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc[V4], sh[V4], mu[V4], is[V4], s1[V4], s2[V4];
+#pragma unroll
+  for (int k = 0; k < V4; ++k) {
+    sc[k] = ld4(scale + c + 4 * k); sh[k] = ld4(shift + c + 4 * k); mu[k] = ld4(mean + c + 4 * k); is[k] = ld4(invstd + c + 4 * k);
+    s1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // (n, y, x) of the thread's first pixel once; then advanced by rpp pixels per iteration (no divisions in the loop)
   long long r = r_begin + trow;
   int x = (int)(r % Wi);
@@ -824,84 +896,99 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
   long long n = tq / Hi;
   const int dq = rpp / Wi, dr = rpp - dq * Wi;     // rpp = dq * Wi + dr
   for (; r < r_end; r += rpp) {
-    const f32x4 y = lds4(Y + r * C + c);
-    const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C / 4);
+    f32x4 y[V4], dz[V4];
+    ldv_stream<V4>(Y + r * C + c, y);
+    pool_gradv<T>(dP, amax, n, yy, x, cv, Ho, Wo, C / V, dz);
     x += dr; yy += dq;
     if (x >= Wi) { x -= Wi; ++yy; }
     while (yy >= Hi) { yy -= Hi; ++n; }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
-      s1[e] += g;
-      s2[e] = fmaf(g, (y[e] - mu[e]) * is[e], s2[e]);
-    }
+    for (int k = 0; k < V4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = fmaf(y[k][e], sc[k][e], sh[k][e]) > 0.f ? dz[k][e] : 0.f;
+        s1[k][e] += g;
+        s2[k][e] = fmaf(g, (y[k][e] - mu[k][e]) * is[k][e], s2[k][e]);
+      }
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+#pragma unroll
+  for (int k = 0; k < V4; ++k) { red[0][k][threadIdx.x] = s1[k]; red[1][k][threadIdx.x] = s2[k]; }
   __syncthreads();
   if (trow == 0) {
-    for (int k = 1; k < rpp; ++k) {
-      s1 += red[0][k * cpb4 + tcol];
-      s2 += red[1][k * cpb4 + tcol];
+    for (int q = 1; q < rpp; ++q)
+#pragma unroll
+      for (int k = 0; k < V4; ++k) { s1[k] += red[0][k][q * cpb + tcol]; s2[k] += red[1][k][q * cpb + tcol]; }
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+      st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c + 4 * k, s1[k]);
+      st4(partials + ((long long)blockIdx.x * 2 + 1) * C + c + 4 * k, s2[k]);
     }
-    st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c, s1);
-    st4(partials + ((long long)blockIdx.x * 2 + 1) * C + c, s2);
   }
 }
 
 // pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool. One image row (n, y) per block: the pixel /
-// channel-vector split of an item is a shift (C4 is a power of two), so there is no integer division per element.
+// channel-vector split of an item is a shift (CV is a power of two), so there is no integer division per element.
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
                                                                  const T* __restrict__ Y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ c1,
-                                                                 const float* __restrict__ c2, T* __restrict__ dY, int C4, int c4_log2,
+                                                                 const float* __restrict__ c2, T* __restrict__ dY, int CV, int cv_log2,
                                                                  int Hi, int Wi, int Ho, int Wo) {
+  constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
   const int yy = blockIdx.x % Hi;
   const long long n = blockIdx.x / Hi;
-  const long long row0 = (long long)blockIdx.x * Wi * C4;     // first float4 item of this image row
-  const int items = Wi * C4;
-  // C4 divides 256 (launcher): the thread's channel vector, hence its six coefficient vectors, are loop-invariant
-  const int c4 = threadIdx.x & (C4 - 1);
-  const int c = c4 * 4;
-  const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
-  const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
-  for (int it = threadIdx.x; it < items; it += 256) {
-    const int x = it >> c4_log2;
-    const long long i = row0 + it;
-    const f32x4 y = lds4(Y + i * 4);
-    const f32x4 dz = pool_grad4<T>(dP, amax, n, yy, x, c4, Ho, Wo, C4);
-    f32x4 o;
+  const long long row0 = (long long)blockIdx.x * Wi * CV;     // first vector item of this image row
+  const int items = Wi * CV;
+  // CV divides 256 (launcher): the thread's channel vector, hence its six coefficient vectors, are loop-invariant
+  const int cv = threadIdx.x & (CV - 1);
+  const int c = cv * V;
+  f32x4 sc[V4], sh[V4], mu[V4], is[V4], k1[V4], k2[V4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float g = fmaf(y[e], sc[e], sh[e]) > 0.f ? dz[e] : 0.f;
-      const float yh = (y[e] - mu[e]) * is[e];
-      o[e] = sc[e] * (g - k1[e] - yh * k2[e]);
-    }
-    sts4(dY + i * 4, o);
+  for (int k = 0; k < V4; ++k) {
+    sc[k] = ld4(scale + c + 4 * k); sh[k] = ld4(shift + c + 4 * k); mu[k] = ld4(mean + c + 4 * k); is[k] = ld4(invstd + c + 4 * k);
+    k1[k] = ld4(c1 + c + 4 * k); k2[k] = ld4(c2 + c + 4 * k);
+  }
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int x = it >> cv_log2;
+    const long long i = row0 + it;
+    f32x4 y[V4], dz[V4], o[V4];
+    ldv_stream<V4>(Y + i * V, y);
+    pool_gradv<T>(dP, amax, n, yy, x, cv, Ho, Wo, CV, dz);
+#pragma unroll
+    for (int k = 0; k < V4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = fmaf(y[k][e], sc[k][e], sh[k][e]) > 0.f ? dz[k][e] : 0.f;
+        const float yh = (y[k][e] - mu[k][e]) * is[k][e];
+        o[k][e] = sc[k][e] * (g - k1[k][e] - yh * k2[k][e]);
+      }
+    stv<V4>(dY + i * V, o, true);
   }
 }
 
-// rows of the partial buffer the pooled reduce writes (always the 4-channels-per-thread geometry)
-int bn_bwd_pool_partial_rows(long long rows, int C) {
-  int cpb4, rpb, nblk;
-  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
+// rows of the partial buffer the pooled reduce writes
+int bn_bwd_pool_partial_rows(long long rows, int C, int dt) {
+  int cpb, rpb, nblk;
+  if (dt == DT_BF16) bwd_geometry16(rows, C, &cpb, &rpb, &nblk);
+  else bwd_geometry(rows, C, &cpb, &rpb, &nblk);
   return nblk;
 }
 
 int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
                               hipStream_t s) {
-  R3M_REQUIRE(is_pow2(C) && C >= 4, "bn_bwd_reduce_pool: C=%d must be a power of two >= 4", C);
+  R3M_REQUIRE(is_pow2(C) && C >= 8, "bn_bwd_reduce_pool: C=%d must be a power of two >= 8", C);
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
   const long long rows = (long long)N * Hi * Wi;
-  int cpb4, rpb, nblk;
-  bwd_geometry(rows, C, &cpb4, &rpb, &nblk);
-  DT_DISPATCH(dt, "bn_bwd_reduce_pool",
-              hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), dim3(nblk, ceil_div(C / 4, cpb4)), dim3(256), 0, s,
-                                 static_cast<const T*>(dP), amax, static_cast<const T*>(Y), scale, shift, mean, invstd, partials, rows, C,
-                                 cpb4, rpb, Hi, Wi, Ho, Wo));
+  int cpb, rpb, nblk;
+  if (dt == DT_BF16) bwd_geometry16(rows, C, &cpb, &rpb, &nblk);
+  else bwd_geometry(rows, C, &cpb, &rpb, &nblk);
+  DT_DISPATCH(dt, "bn_bwd_reduce_pool", {
+    constexpr int V = 4 * PoolVec<T>::V4;
+    hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), dim3(nblk, ceil_div(C / V, cpb)), dim3(256), 0, s, static_cast<const T*>(dP),
+                       amax, static_cast<const T*>(Y), scale, shift, mean, invstd, partials, rows, C, cpb, rpb, Hi, Wi, Ho, Wo);
+  });
   return check_launch("bn_bwd_reduce_pool");
 }
 
@@ -909,13 +996,14 @@ int launch_bn_bwd_apply_pool(const void* dP, const unsigned char* amax, const vo
                              const float* mean, const float* invstd, const float* c1, const float* c2, void* dY, int N, int Hi, int Wi,
                              int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-  R3M_REQUIRE(is_pow2(C) && C >= 4 && C <= 1024, "bn_bwd_apply_pool: C=%d must be a power of two in [4, 1024]", C);
-  int c4_log2 = 0;
-  while ((1 << c4_log2) < C / 4) ++c4_log2;
-  DT_DISPATCH(dt, "bn_bwd_apply_pool",
-              hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(N * Hi), dim3(256), 0, s, static_cast<const T*>(dP), amax,
-                                 static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), C / 4, c4_log2, Hi, Wi,
-                                 Ho, Wo));
+  R3M_REQUIRE(is_pow2(C) && C >= 8 && C <= 1024, "bn_bwd_apply_pool: C=%d must be a power of two in [8, 1024]", C);
+  DT_DISPATCH(dt, "bn_bwd_apply_pool", {
+    constexpr int V = 4 * PoolVec<T>::V4;
+    int cv_log2 = 0;
+    while ((1 << cv_log2) < C / V) ++cv_log2;
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(N * Hi), dim3(256), 0, s, static_cast<const T*>(dP), amax,
+                       static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), C / V, cv_log2, Hi, Wi, Ho, Wo);
+  });
   return check_launch("bn_bwd_apply_pool");
 }
 

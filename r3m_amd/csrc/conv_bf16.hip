@@ -45,15 +45,23 @@ __device__ __forceinline__ void dma16(const char* src, unsigned char* lds) {
 //     with 8 waves x 8 KB outstanding per CU (tools/micro/l2dma.hip) against the ~6 TB/s these kernels draw, but one block
 //     per CU loses more in uncovered prologue/epilogue than the deeper ring wins
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN, int EPI, int NST>
+// BK = K elements per tile: 64 (128-byte LDS rows, 8 rows per DMA instruction, 16-byte slots swizzled by (row>>1)&7) or
+// 32 (64-byte rows, 16 rows per instruction, slots swizzled by (row>>2)&3 — also conflict-free for ds_read_b128). BK = 32 halves
+// the ring (2 x 16 KB for 128 x 128), so the block's LDS is its 37 KB epilogue slab and THREE blocks share a CU.
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64>
 __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);  // DMA instructions per wave per tile (8 rows each)
-  static_assert(AJ * 8 * NW == BM && BJ * 8 * NW == BN, "every wave stages whole 8-row groups");
+  constexpr int RB = BK * 2;                             // bytes per LDS row
+  constexpr int RPI = 1024 / RB;                         // rows per DMA instruction (8 or 16)
+  constexpr int SPR = RB / 16;                           // 16-byte slots per row (8 or 4)
+  constexpr int NG = BK / 16;                            // MFMA K groups per tile (4 or 2)
+  constexpr int AJ = BM / (RPI * NW), BJ = BN / (RPI * NW);  // DMA instructions per wave per tile
+  static_assert(BK == 64 || BK == 32, "K tile of 64 or 32");
+  static_assert(AJ * RPI * NW == BM && BJ * RPI * NW == BN, "every wave stages whole DMA row groups");
   static_assert(NST >= 1 && NST <= 3, "ring of 1 (single K tile launches only), 2 or 3 stages");
   constexpr int NP = AJ + BJ;
-  constexpr int STAGE = (BM + BN) * 128;                 // bytes
+  constexpr int STAGE = (BM + BN) * RB;                  // bytes
   extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -67,7 +75,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
 
-  const int srow = lane >> 3, pslot = lane & 7;
+  const int srow = lane / SPR, pslot = lane % SPR;
+  auto swz = [](int r) __attribute__((always_inline)) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
   const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
   RowDesc ad[AJ];
   int acol[AJ];                        // byte offset inside the 128-byte K chunk this lane fetches (swizzled)
@@ -75,21 +84,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   const char* bptr[BJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int r = wave * (BM / NW) + j * 8 + srow;
-    acol[j] = (pslot ^ ((r >> 1) & 7)) * 16;
+    const int r = wave * (BM / NW) + j * RPI + srow;
+    acol[j] = (pslot ^ swz(r)) * 16;
     const int m = m0 + r;
     ad[j] = decode_row(p, m);
     if (m < p.M) arow_ok |= 1u << j;
   }
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int r = wave * (BN / NW) + j * 8 + srow;
+    const int r = wave * (BN / NW) + j * RPI + srow;
     const int n = min(n0 + r, p.Nc - 1);                  // columns past Nc are computed on a clamped row, never stored
-    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ ((r >> 1) & 7)) * 16;
+    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ swz(r)) * 16;
   }
   const char* zline = reinterpret_cast<const char*>(g_zero_bytes) + pslot * 16;
 
-  const int kpt = p.Ci >> 6;          // K tiles per tap
+  const int kpt = p.Ci / BK;          // K tiles per tap
   const int nk = p.ntaps * kpt;
 
   // issue cursor: the tile the next DMA pieces belong to
@@ -107,9 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   // one DMA piece of the cursor's tile into ring slot `stage`
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
-    const int c0b = chunk_n * 128;
-    unsigned char* la = smem + stage * STAGE + wave * (BM / NW) * 128;
-    unsigned char* lb = smem + stage * STAGE + BM * 128 + wave * (BN / NW) * 128;
+    const int c0b = chunk_n * RB;
+    unsigned char* la = smem + stage * STAGE + wave * (BM / NW) * RB;
+    unsigned char* lb = smem + stage * STAGE + BM * RB + wave * (BN / NW) * RB;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
@@ -117,11 +126,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
       const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
       const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
       const char* src = Ab + (ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci) * 2 + c0b + acol[j];
-      dma16(sel_ptr(src, zline, in), la + j * 8 * 128);
+      dma16(sel_ptr(src, zline, in), la + j * 1024);
     } else {
       constexpr int j = pc - AJ;
       const int wt = pack_cur >> 16;
-      dma16(bptr[j] + (long long)wt * p.Ci * 2 + c0b, lb + j * 8 * 128);
+      dma16(bptr[j] + (long long)wt * p.Ci * 2 + c0b, lb + j * 1024);
     }
   };
 
@@ -135,12 +144,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
 
   // fragment addressing: row = lrow (+32 per MFMA tile), logical slot 2g+h, physical slot = logical ^ ((row>>1)&7)
   const int lrow = lane & 31, lh = lane >> 5;
-  const int xr = (lrow >> 1) & 7;
-  int goff[4];
+  const int xr = swz(lrow);           // tile row offsets are multiples of 32: the swizzle key only depends on lrow
+  int goff[NG];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) goff[g] = ((2 * g + lh) ^ xr) * 16;
-  const unsigned char* fragA0 = smem + (wm * TM * 32 + lrow) * 128;
-  const unsigned char* fragB0 = smem + BM * 128 + (wn * TN * 32 + lrow) * 128;
+  for (int g = 0; g < NG; ++g) goff[g] = ((2 * g + lh) ^ xr) * 16;
+  const unsigned char* fragA0 = smem + (wm * TM * 32 + lrow) * RB;
+  const unsigned char* fragB0 = smem + BM * RB + (wn * TN * 32 + lrow) * RB;
 
   // prologue: tiles 0 .. NST-2 (NST == 1: the launch has ONE K tile — 1x1 convs with Cin = 64 — and it is simply loaded; the
   // block then needs 37 instead of 64 KB of LDS, so three blocks share a CU instead of two)
@@ -167,15 +176,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
     // the loads leave the sooner they land (+2..8 % over spreading them between the MFMA groups; probe 4 = spread)
     const bool clustered = (p.debug & 4) == 0;
     if (more && clustered) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(istage, pc); });
-    static_for<4>([&](auto g_c) __attribute__((always_inline)) {
+    static_for<NG>([&](auto g_c) __attribute__((always_inline)) {
       constexpr int g = decltype(g_c)::value;
       bf16x8 a[TM], b[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * 128 + goff[g]);
+      for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * RB + goff[g]);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * 128 + goff[g]);
-      if (more && !clustered) {   // DMA pieces of tile kt + NST - 1, spread over the four MFMA groups
-        constexpr int P0 = g * NP / 4, P1 = (g + 1) * NP / 4;
+      for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * RB + goff[g]);
+      if (more && !clustered) {   // DMA pieces of tile kt + NST - 1, spread over the MFMA groups
+        constexpr int P0 = g * NP / NG, P1 = (g + 1) * NP / NG;
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
           issue_piece(istage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
         });
@@ -200,20 +209,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
   }
   if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
   // the launcher sizes the dynamic LDS as max(ring, epilogue slabs): with NST == 1 the slabs are the larger
-  constexpr int SMEM_F = (NST == 1 ? 40960 : NST * STAGE) / 4;
+  constexpr int SMEM_F = (NST * STAGE < 40960 ? 40960 : NST * STAGE) / 4;
   if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, SMEM_F>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
   else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, SMEM_F, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
 }
 
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST>
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK>
 static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
   constexpr int slab = WM * WN * (BM / WM) * (BN / WN + 8) * 2;             // bf16 epilogue slabs (single-pass stores)
   constexpr int slab32 = WM * WN * 32 * (BN / WN + 4) * 4;                  // fp32 slabs of the read-modify-write epilogues
-  constexpr int tiles = NST * (BM + BN) * 128;
+  constexpr int tiles = NST * (BM + BN) * BK * 2;
   constexpr int lds = tiles > slab ? (tiles > slab32 ? tiles : slab32) : (slab > slab32 ? slab : slab32);
-  auto kern = gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI, NST>;
+  auto kern = gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI, NST, BK>;
   static bool attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -226,13 +235,13 @@ static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64>
 static int gg16_launch(const GatherGemmParams& p, int grid, hipStream_t s) {
   switch (p.flags) {
-    case 0: return gg16_launch_one<BM, BN, WM, WN, 0, NST>(p, grid, s);
-    case EPI_STATS: return gg16_launch_one<BM, BN, WM, WN, EPI_STATS, NST>(p, grid, s);
-    case EPI_ACCUM: return gg16_launch_one<BM, BN, WM, WN, EPI_ACCUM, NST>(p, grid, s);
-    case EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD, NST>(p, grid, s);
+    case 0: return gg16_launch_one<BM, BN, WM, WN, 0, NST, BK>(p, grid, s);
+    case EPI_STATS: return gg16_launch_one<BM, BN, WM, WN, EPI_STATS, NST, BK>(p, grid, s);
+    case EPI_ACCUM: return gg16_launch_one<BM, BN, WM, WN, EPI_ACCUM, NST, BK>(p, grid, s);
+    case EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD, NST, BK>(p, grid, s);
     default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }
@@ -253,6 +262,21 @@ static bool gg16_single() {
   return v != 0;
 }
 
+// K tiles of 32 (16 KB stages, three blocks per CU instead of two) for the launches with more than one K tile: measured -4 %
+// on the 128x128 class and -1 % on 256x64 over ResNet-50 (tools/experiments/gpu_bk32.sh). R3M_BF16_BK=64 restores 64.
+static bool gg16_bk32() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_BF16_BK"); v = (e && atoi(e) == 64) ? 0 : 1; }
+  return v != 0;
+}
+
+// R3M_BF16_NST=3: three-stage ring (two tiles in flight) for the 32-wide K tiles; bit 2 (=7) also for the 256x64 tile
+static int gg16_nst() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_BF16_NST"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);
@@ -265,12 +289,16 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s)
-         : (nk == 1 && gg16_single()) ? gg16_launch<128, 128, 2, 2, 1>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
+         : (nk == 1 && gg16_single()) ? gg16_launch<128, 128, 2, 2, 1>(p, grid, s)
+         : gg16_bk32() ? ((gg16_nst() & 3) == 3 ? gg16_launch<128, 128, 2, 2, 3, 32>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2, 32>(p, grid, s))
+                       : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : w8 ? gg16_launch<256, 64, 4, 2, 2>(p, grid, s)
-         : (nk == 1 && gg16_single()) ? gg16_launch<256, 64, 4, 1, 1>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
+         : (nk == 1 && gg16_single()) ? gg16_launch<256, 64, 4, 1, 1>(p, grid, s)
+         : gg16_bk32() ? (gg16_nst() == 7 ? gg16_launch<256, 64, 4, 1, 3, 32>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2, 32>(p, grid, s))
+                       : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
   prof_bytes(gather_gemm_alg_bytes(p, 2));
   prof_end(s);
@@ -287,13 +315,14 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
 // lane 4j + (c >> 2) addressed, for j = 0..3. With lane q = 4j + i addressing k row kb + j, channels cb + 4i..4i+3, lane c
 // receives channel cb + c at k = kb..kb+3: four consecutive k of one channel — half an MFMA operand.
 // =====================================================================================================
-template <int BMt, int BNt>
+template <int BMt, int BNt, int BK = 64>   // BK = rows per K step: 64, or 32 (half the LDS: more blocks per CU)
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
-  constexpr int BK = 64;
+  static_assert(BK == 64 || BK == 32, "K step of 64 or 32 rows");
+  constexpr int WR = BK / 4;                                   // k rows staged per wave per stage
   constexpr int TM = BMt / 64, TN = BNt / 64;
   constexpr int A_ROWB = BMt * 2, B_ROWB = BNt * 2;            // bytes per k row
   constexpr int A_RPI = 1024 / A_ROWB, B_RPI = 1024 / B_ROWB;  // k rows per DMA instruction
-  constexpr int AJ = 16 / A_RPI, BJ = 16 / B_RPI;              // instructions per wave per stage (16 k rows per wave)
+  constexpr int AJ = WR / A_RPI, BJ = WR / B_RPI;              // instructions per wave per stage
   constexpr int NP = AJ + BJ;
   constexpr int STAGE = BK * (A_ROWB + B_ROWB);
   __shared__ __attribute__((aligned(256))) unsigned char smem[2 * STAGE];
@@ -330,10 +359,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   const char* a_ptr[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    a_m[j] = ms + wave * 16 + j * A_RPI + a_k;
+    a_m[j] = ms + wave * WR + j * A_RPI + a_k;
     a_ptr[j] = dYb + (long long)a_m[j] * p.Co * 2 + a_cb;
   }
-  const int q64 = 64 / p.Wo, r64 = 64 - q64 * p.Wo;
+  const int q64 = BK / p.Wo, r64 = BK - q64 * p.Wo;          // (oy, ox) advance of one K step
   const bool fast_adv = (q64 + 1) <= p.Ho;
   const long long img = (long long)p.Hi * p.Wi * p.Ci * 2;
   int b_m[BJ];
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   int xoy[BJ], xox[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    b_m[j] = ms + wave * 16 + j * B_RPI + b_k;
+    b_m[j] = ms + wave * WR + j * B_RPI + b_k;
     xoy[j] = 0; xox[j] = 0;
     if (p.simple_rows) {
       b_ptr[j] = Xb + (long long)b_m[j] * p.Ci * 2 + b_cb;
@@ -353,19 +382,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
       b_ptr[j] = Xb + (long long)n * img + b_cb;
     }
   }
-  const long long a_step = 64LL * p.Co * 2, b_step = 64LL * p.Ci * 2;
+  const long long a_step = (long long)BK * p.Co * 2, b_step = (long long)BK * p.Ci * 2;
 
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
-      unsigned char* la = smem + stage * STAGE + (wave * 16 + j * A_RPI) * A_ROWB;
+      unsigned char* la = smem + stage * STAGE + (wave * WR + j * A_RPI) * A_ROWB;
       dma16(sel_ptr(a_ptr[j], zl, a_m[j] < me), la);
-      a_m[j] += 64;
+      a_m[j] += BK;
       a_ptr[j] += a_step;
     } else {
       constexpr int j = pc - AJ;
-      unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * 16 + j * B_RPI) * B_ROWB;
+      unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * WR + j * B_RPI) * B_ROWB;
       const char* src;
       if (p.simple_rows) {
         src = sel_ptr(b_ptr[j], zl, b_m[j] < me);
@@ -384,7 +413,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
           b_ptr[j] = cy ? b_ptr[j] + img : b_ptr[j];
           xox[j] = ox; xoy[j] = oy;
         } else {
-          const int m = b_m[j] + 64;
+          const int m = b_m[j] + BK;
           const int n = m / hw;
           const int rem = m - n * hw;
           xoy[j] = rem / p.Wo;
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
         }
       }
       dma16(src, lb);
-      b_m[j] += 64;
+      b_m[j] += BK;
     }
   };
 
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   auto mfma_stage = [&](const unsigned char* st, int dma_stage) __attribute__((always_inline)) {
     // the next K step's DMA: all pieces right after the barrier (p.interleave = 1: spread between the MFMA groups instead)
     if (dma_stage >= 0 && !p.interleave) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(dma_stage, pc); });
-    static_for<4>([&](auto s_c) __attribute__((always_inline)) {
+    static_for<BK / 16>([&](auto s_c) __attribute__((always_inline)) {
       constexpr int sidx = decltype(s_c)::value;
       bf16x8 a[TM], b[TN];
 #pragma unroll
@@ -440,7 +469,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
 #pragma unroll
       for (int t = 0; t < TN; ++t) b[t] = frag(st + fb_off[t], B_ROWB, sidx);
       if (dma_stage >= 0 && p.interleave) {
-        constexpr int P0 = sidx * NP / 4, P1 = (sidx + 1) * NP / 4;
+        constexpr int P0 = sidx * NP / (BK / 16), P1 = (sidx + 1) * NP / (BK / 16);
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
           issue_piece(dma_stage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
         });
@@ -483,7 +512,9 @@ static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128
 int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   const bool wide = wg_wide(Co, Ci);
   const int tiles = wide ? (Co / 128) * (Ci / 128) * T : ceil_div(Co, 64) * ceil_div(Ci, 64) * T;
-  int split = (wide ? 1024 : 2560) / (tiles > 0 ? tiles : 1);
+  static int tgt = -1;     // R3M_WG16_BLOCKS: target block count of the 128x128 launches (experiments)
+  if (tgt < 0) { const char* e = getenv("R3M_WG16_BLOCKS"); tgt = e ? atoi(e) : 0; }
+  int split = (wide ? (tgt > 0 ? tgt : 1024) : 2560) / (tiles > 0 ? tiles : 1);
   const int max_split = ceil_div(M, 256);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -510,7 +541,14 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
     p.xcd = xc;
   }
   const dim3 grid(p.gx * splitK);
-  if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+  // K steps of 32 rows for the 128x128 tile (32 KB of stages instead of 64: -16 % measured over ResNet-50), 64 rows for the
+  // 64x64 tile (32 rows measured +5 % there). R3M_WG16_BK=64 / =32 forces one step size on both (experiments).
+  static int bk = -1;
+  if (bk < 0) { const char* e = getenv("R3M_WG16_BK"); bk = e ? atoi(e) : 0; }
+  const bool bk32 = bk == 32 || (bk != 64 && wide);
+  if (wide && bk32) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32>), grid, dim3(256), 0, s, p);
+  else if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+  else if (bk32) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64, 32>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, s, p);
   prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
   prof_end(s);
