@@ -48,8 +48,22 @@ __device__ __forceinline__ void dma16(const char* src, unsigned char* lds) {
 // BK = K elements per tile: 64 (128-byte LDS rows, 8 rows per DMA instruction, 16-byte slots swizzled by (row>>1)&7) or
 // 32 (64-byte rows, 16 rows per instruction, slots swizzled by (row>>2)&3 — also conflict-free for ds_read_b128). BK = 32 halves
 // the ring (2 x 16 KB for 128 x 128), so the block's LDS is its 37 KB epilogue slab and THREE blocks share a CU.
+//
+// Register budget: the configurations whose LDS is just the 37-40 KB epilogue slab (32-wide K tiles; single stage) can share a CU
+// three or four ways, but left alone the compiler gives the plain-store epilogue 117-152 VGPRs + 64 AGPRs = two waves per SIMD.
+// __launch_bounds__'s second argument states the blocks per CU the kernel is budgeted for (168 registers per lane for three, 128
+// for four — the latter with 8-56 bytes of scratch in the epilogue, still the faster choice for the 128x128 tile).
+#ifndef R3M_GG16_OCC_WIDE
+#define R3M_GG16_OCC_WIDE 4      // 128x128 tile (0 = compiler's choice)
+#endif
+#ifndef R3M_GG16_OCC_NARROW
+#define R3M_GG16_OCC_NARROW 3    // 256x64 tile
+#endif
 template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64>
-__global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const GatherGemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (BM == 256 && BN == 128) ? (BK == 32 ? 2 : 1)
+                                           : !(BK == 32 || NST == 1) ? 1
+                                           : (BN == 128 ? (R3M_GG16_OCC_WIDE ? R3M_GG16_OCC_WIDE : 1) : (R3M_GG16_OCC_NARROW ? R3M_GG16_OCC_NARROW : 1)))
+void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int RB = BK * 2;                             // bytes per LDS row
@@ -207,7 +221,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_bf16_kernel(const Ga
     if (acc[0][0][0] + acc[TM - 1][TN - 1][3] == 123.456f) reinterpret_cast<float*>(p.out)[0] = 1.f;
     return;
   }
-  if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
+  // a 256-row tile writes one partial row per 128-row half (same partial geometry as the 128-row tiles)
+  if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN, (BM == 256 && BN == 128)>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
   // the launcher sizes the dynamic LDS as max(ring, epilogue slabs): with NST == 1 the slabs are the larger
   constexpr int SMEM_F = (NST * STAGE < 40960 ? 40960 : NST * STAGE) / 4;
   if ((p.Nc & 7) == 0) gg_store_bf16<BM, BN, WM, WN, EPI, SMEM_F>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
@@ -218,7 +233,7 @@ static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK>
 static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
-  constexpr int slab = WM * WN * (BM / WM) * (BN / WN + 8) * 2;             // bf16 epilogue slabs (single-pass stores)
+  constexpr int slab = WM * WN * (BM / WM > 64 ? 64 : BM / WM) * (BN / WN + 8) * 2;   // bf16 epilogue slabs (64 rows per wave and pass)
   constexpr int slab32 = WM * WN * 32 * (BN / WN + 4) * 4;                  // fp32 slabs of the read-modify-write epilogues
   constexpr int tiles = NST * (BM + BN) * BK * 2;
   constexpr int lds = tiles > slab ? (tiles > slab32 ? tiles : slab32) : (slab > slab32 ? slab : slab32);
@@ -262,18 +277,28 @@ static bool gg16_single() {
   return v != 0;
 }
 
-// K tiles of 32 (16 KB stages, three blocks per CU instead of two) for the launches with more than one K tile: measured -4 %
-// on the 128x128 class and -1 % on 256x64 over ResNet-50 (tools/experiments/gpu_bk32.sh). R3M_BF16_BK=64 restores 64.
-static bool gg16_bk32() {
+// K tile width of a multi-tile launch. 32 (16 KB stages, THREE blocks per CU instead of two) wins where the epilogue is a large
+// part of a block's life — the expanding 1x1 convs and everything with a read-modify-write epilogue: -10..-33 % per launch on
+// ResNet-50 — because a third resident block covers it; 64 (half the barriers per K) wins by 3..16 % where the main loop
+// dominates: K >= 4 N, i.e. the 3x3 convs and the contracting 1x1 convs (per-shape table: tools/experiments/gpu_bk32b.sh).
+// The 256x64 tile's 3x3 launches are the exception (measured -4 % with 32). R3M_BF16_BK=32 / 64 forces one width.
+static bool gg16_bk32(const GatherGemmParams& p, bool wide) {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_BK"); v = (e && atoi(e) == 64) ? 0 : 1; }
-  return v != 0;
+  if (v < 0) { const char* e = getenv("R3M_BF16_BK"); v = e ? atoi(e) : 0; }
+  if (v == 32) return true;
+  if (v == 64) return false;
+  const long long ktot = (long long)p.ntaps * p.Ci;
+  const bool mainloop_bound = ktot >= 4LL * p.Nc && (wide || p.ntaps == 1);
+  return !mainloop_bound;
 }
 
-// R3M_BF16_NST=3: three-stage ring (two tiles in flight) for the 32-wide K tiles; bit 2 (=7) also for the 256x64 tile
-static int gg16_nst() {
+// 256 x 128 block tile (waves 2 x 2, 128 x 64 per wave) for the main-loop-bound wide launches: a 64 x 64 wave tile reads
+// (64 + 64) x 32 B of fragments per 4 MFMAs — with 8 waves per CU that is exactly the LDS's 128 B/clk, so those launches sat at
+// ~35 % of the MFMA peak; 128 x 64 per wave needs 0.75x the fragment bytes per flop. R3M_BF16_BIG=0 disables, =64 uses 64-wide
+// K tiles (96 KB ring, one block per CU) instead of 32-wide (48 KB, two blocks).
+static int gg16_big() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_NST"); v = e ? atoi(e) : 2; }
+  if (v < 0) { const char* e = getenv("R3M_BF16_BIG"); v = e ? atoi(e) : 0; }
   return v;
 }
 
@@ -288,17 +313,19 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    rc = ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s)
+    // R3M_BF16_BIG < 0: every multi-tile wide launch (tests)
+    const bool big = gg16_big() < 0 ? nk >= 2 : gg16_big() != 0 && !gg16_bk32(p, true) && nk >= 4 && p.M >= 256 * 256;
+    const int gridb = ceil_div(p.M, 256) * ceil_div(p.Nc, 128);
+    rc = big ? (gg16_big() == 64 ? gg16_launch<256, 128, 2, 2, 2, 64>(p, gridb, s) : gg16_launch<256, 128, 2, 2, 2, 32>(p, gridb, s))
+         : ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s)
          : (nk == 1 && gg16_single()) ? gg16_launch<128, 128, 2, 2, 1>(p, grid, s)
-         : gg16_bk32() ? ((gg16_nst() & 3) == 3 ? gg16_launch<128, 128, 2, 2, 3, 32>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2, 32>(p, grid, s))
-                       : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
+         : gg16_bk32(p, true) ? gg16_launch<128, 128, 2, 2, 2, 32>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     rc = ring ? gg16_launch<256, 64, 4, 2, 3>(p, grid, s) : w8 ? gg16_launch<256, 64, 4, 2, 2>(p, grid, s)
          : (nk == 1 && gg16_single()) ? gg16_launch<256, 64, 4, 1, 1>(p, grid, s)
-         : gg16_bk32() ? (gg16_nst() == 7 ? gg16_launch<256, 64, 4, 1, 3, 32>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2, 32>(p, grid, s))
-                       : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
+         : gg16_bk32(p, false) ? gg16_launch<256, 64, 4, 1, 2, 32>(p, grid, s) : gg16_launch<256, 64, 4, 1, 2>(p, grid, s);
   }
   prof_bytes(gather_gemm_alg_bytes(p, 2));
   prof_end(s);

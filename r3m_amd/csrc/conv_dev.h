@@ -65,8 +65,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// BatchNorm partials of one block tile: per-column sum / sum of squares over the block's rows -> stats[mt][2][Nc]
-template <int BM, int BN, int WM, int WN>
+// BatchNorm partials of one block tile: per-column sum / sum of squares over the block's rows -> stats[mt][2][Nc].
+// PER_WM: every wave row writes its own partial row (stats[mt * WM + wm]) — a 256-row tile then produces the same partial-row
+// geometry as two 128-row tiles, and the engine's row count does not depend on the tile the launcher picks.
+template <int BM, int BN, int WM, int WN, bool PER_WM = false>
 __device__ __forceinline__ void gg_stats(const GatherGemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, int n0,
                                          int mt) {
   constexpr int TM = BM / WM / 32;
@@ -91,12 +93,20 @@ __device__ __forceinline__ void gg_stats(const GatherGemmParams& p, f32x16 (&acc
         }
       s += __shfl_xor(s, 32);
       ss += __shfl_xor(ss, 32);
-      if (lane < 32) {
+      if (PER_WM) {
+        const int col = n0 + (wn * TN + tn) * 32 + lane;
+        const long long prow = (long long)mt * WM + wm;
+        if (lane < 32 && col < p.Nc && prow * (BM / WM) < p.M) {
+          p.stats[(prow * 2 + 0) * p.Nc + col] = s;
+          p.stats[(prow * 2 + 1) * p.Nc + col] = ss;
+        }
+      } else if (lane < 32) {
         const int c = (wn * TN + tn) * 32 + lane;
         red[(wm * 2 + 0) * BN + c] = s;
         red[(wm * 2 + 1) * BN + c] = ss;
       }
     }
+    if (PER_WM) return;
     __syncthreads();
     if (tid < BN) {
       float s = 0.f, ss = 0.f;
@@ -238,22 +248,28 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
   };
   if constexpr (!RMW) {
     constexpr int CSH = CW + 8;          // slab row stride in bf16 (16-byte aligned rows, 4-bank skew)
-    static_assert(WM * WN * TM * 32 * CSH * 2 <= SMEM_FLOATS * 4, "epilogue slab must fit in the operand tiles' LDS");
-    bf16_t* slab = reinterpret_cast<bf16_t*>(smem) + wave * TM * 32 * CSH;
+    constexpr int TMP = TM > 2 ? 2 : TM; // row tiles per pass (64 slab rows per wave at most)
+    static_assert(TM % TMP == 0, "whole passes");
+    static_assert(WM * WN * TMP * 32 * CSH * 2 <= SMEM_FLOATS * 4, "epilogue slab must fit in the operand tiles' LDS");
+    bf16_t* slab = reinterpret_cast<bf16_t*>(smem) + wave * TMP * 32 * CSH;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int ps = 0; ps < TM / TMP; ++ps) {
+      if (ps) __builtin_amdgcn_wave_barrier();   // the previous pass's slab reads are done (in-order LDS per wave)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int tm = 0; tm < TMP; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[tm][tn][r];
-    __builtin_amdgcn_wave_barrier();
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-    for (int it = 0; it < TM * 32 / RPI; ++it) {
-      const int lr = it * RPI + erow;
-      const int row = m0 + wm * TM * 32 + lr;
-      if (row < p.M && gcol < p.Nc)
-        st8_out(outp + row_off(row) + gcol, *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol));
+          for (int r = 0; r < 16; ++r)
+            slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[ps * TMP + tm][tn][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < TMP * 32 / RPI; ++it) {
+        const int lr = it * RPI + erow;
+        const int row = m0 + (wm * TM + ps * TMP) * 32 + lr;
+        if (row < p.M && gcol < p.Nc)
+          st8_out(outp + row_off(row) + gcol, *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol));
+      }
     }
   } else {
     constexpr int CS = CW + 4;           // padded slab row stride (floats)
