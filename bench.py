@@ -75,8 +75,8 @@ def cpu_baseline(size, clips, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)      # >= 20 timed steps after >= 5 warm-ups
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=50)
     ap.add_argument("--clips-per-gpu", type=int, default=256, help="clips per GPU (5 frames each); BASELINE bs=256")
     ap.add_argument("--langweight", type=float, default=0.0, help="> 0: BASELINE configs[2] (language head on frozen text features)")

@@ -35,19 +35,20 @@ __device__ __forceinline__ void dma16(const char* src, unsigned char* lds) {
 }
 
 // =====================================================================================================
-// gather-GEMM on bf16 operands. Block BM x BN, K step 64 (one 128-byte row per GEMM row), WM x WN waves.
-// LDS: a ring of NST stages of {A[BM][64], B[BN][64]} bf16 (dynamic LDS, NST * (BM+BN) * 128 bytes). Tile t + NST - 1 is
-// issued (DMA pieces spread between the MFMA groups of tile t) right after the barrier that publishes tile t, so up to
-// NST - 1 tiles are in flight per block; a wave waits only for ITS pieces of the oldest tile (s_waitcnt vmcnt(pieces of the
-// newer tile), loads retire in order). Two configurations are used:
-//   4 waves, 2 stages (64 KB, 2 blocks/CU)   — the production configuration
-//   8 waves, 3 stages (96-120 KB, 1 block/CU) — experiment (R3M_BF16_RING): the L2 -> LDS DMA path itself delivers 17 TB/s
-//     with 8 waves x 8 KB outstanding per CU (tools/micro/l2dma.hip) against the ~6 TB/s these kernels draw, but one block
-//     per CU loses more in uncovered prologue/epilogue than the deeper ring wins
+// gather-GEMM on bf16 operands. Block BM x BN, K tiles of BK elements (one LDS row per GEMM row), WM x WN waves.
+// LDS: a ring of NST stages of {A[BM][BK], B[BN][BK]} bf16 (dynamic LDS). Tile t + NST - 1 is issued right after the barrier that
+// publishes tile t (all DMA pieces at once: with the 16x faster MFMA there is no issue cost worth hiding), so up to NST - 1 tiles
+// are in flight per block; a wave waits only for ITS pieces of the oldest tile (s_waitcnt vmcnt(pieces of the newer tile), loads
+// retire in order). BK = 64: 128-byte rows, 8 rows per DMA instruction, 16-byte slots swizzled by (row>>1)&7; BK = 32: 64-byte
+// rows, 16 rows per instruction, slots swizzled by (row>>2)&3 — also conflict-free for ds_read_b128. Configurations in use
+// (launch_gather_gemm_bf16 picks per shape):
+//   4 waves, 2 stages, BK = 64 (64-80 KB: 2 blocks/CU)   — main-loop-bound launches: 3x3 convs, contracting 1x1 convs
+//   4 waves, 2 stages, BK = 32 (ring 32-40 KB <= the epilogue slab: 3-4 blocks/CU) — expanding 1x1 convs, read-modify-write epilogues
+//   4 waves, 1 stage,  BK = 64 (launches with ONE K tile: 1x1 convs with Cin = 64; LDS = the epilogue slab)
+//   experiments: 256x128 tile (R3M_BF16_BIG), 8 waves with a 3-stage ring at 1 block/CU (R3M_BF16_RING: the L2 -> LDS DMA path
+//     delivers 17 TB/s with 8 waves x 8 KB outstanding per CU, tools/micro/l2dma.hip, but one block per CU loses more in uncovered
+//     prologue/epilogue than the deeper ring wins) — measurements in DESIGN.md section 5
 // =====================================================================================================
-// BK = K elements per tile: 64 (128-byte LDS rows, 8 rows per DMA instruction, 16-byte slots swizzled by (row>>1)&7) or
-// 32 (64-byte rows, 16 rows per instruction, slots swizzled by (row>>2)&3 — also conflict-free for ds_read_b128). BK = 32 halves
-// the ring (2 x 16 KB for 128 x 128), so the block's LDS is its 37 KB epilogue slab and THREE blocks share a CU.
 //
 // Register budget: the configurations whose LDS is just the 37-40 KB epilogue slab (32-wide K tiles; single stage) can share a CU
 // three or four ways, but left alone the compiler gives the plain-store epilogue 117-152 VGPRs + 64 AGPRs = two waves per SIMD.

@@ -10,6 +10,22 @@ import json
 import re
 import sys
 
+def short_name(k):
+    """kernel-trace names of kernels with bf16 arguments come back mangled (the tracer's demangler does not know DF16b): keep
+    namespace-less function name + template arguments in their mangled form"""
+    m = re.match(r"_ZN3r3m(\d+)", k)
+    if not m:
+        return k
+    n = int(m.group(1))
+    name = k[m.end():m.end() + n]
+    rest = k[m.end() + n:]
+    t = re.match(r"I(.*?)EEv", rest)
+    if t:
+        args = re.findall(r"Li(\d+)E|(DF16b)|(f)", t.group(1))
+        name += "<" + ", ".join(a or ("bf16" if b else "float") for a, b, c in args) + ">"
+    return name
+
+
 d, outp = sys.argv[1], sys.argv[2]
 sfx = sys.argv[3] if len(sys.argv) > 3 else ""
 json_name = sys.argv[4] if len(sys.argv) > 4 else "pmc_latest.json"
@@ -33,8 +49,9 @@ for i in range(1, 5):
 
 
 def group(k):
-    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<128, 128, 2, 2, \d+(, \d+)?>", "gather_gemm 128x128 (all epilogues)", k)
-    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<256, 64, 4, 1, \d+(, \d+)?>", "gather_gemm 256x64 (all epilogues)", k)
+    k = short_name(k)
+    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<128, 128, 2, 2, \d+(, \d+)*>", "gather_gemm 128x128 (all epilogues)", k)
+    k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<256, 64, 4, 1, \d+(, \d+)*>", "gather_gemm 256x64 (all epilogues)", k)
     return k
 
 

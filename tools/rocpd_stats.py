@@ -5,8 +5,25 @@ import re
 import sqlite3
 import sys
 
+def short_name(k):
+    """kernel-trace names of kernels with bf16 arguments come back mangled (the tracer's demangler does not know DF16b): keep
+    namespace-less function name + template arguments in their mangled form"""
+    m = re.match(r"_ZN3r3m(\d+)", k)
+    if not m:
+        return k
+    n = int(m.group(1))
+    name = k[m.end():m.end() + n]
+    rest = k[m.end() + n:]
+    t = re.match(r"I(.*?)EEv", rest)
+    if t:
+        args = re.findall(r"Li(\d+)E|(DF16b)|(f)", t.group(1))
+        name += "<" + ", ".join(a or ("bf16" if b else "float") for a, b, c in args) + ">"
+    return name
+
+
 
 def short(name):
+    name = short_name(name)
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("r3m::", "")
     return name[:110]
