@@ -137,6 +137,8 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
+      if ((p.debug & 8) && dx != 0) return;     // probe 8: stage the A tile of the centre-column taps only (bytes-per-flop what-if)
+      if ((p.debug & 16) && (dx != 0 || dy != 0)) return;   // probe 16: ... of the centre tap only
       const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
       const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
       const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
@@ -230,6 +232,223 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   else gg_epilogue<BM, BN, WM, WN, EPI & ~EPI_STATS, SMEM_F, bf16_t>(p, acc, reinterpret_cast<float*>(smem), m0, n0, mt);
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolutions (forward and dgrad) with a HALO tile: the nine taps of a tile of BM consecutive output
+// pixels read input pixels m0 - (W+1) .. m0 + BM - 1 + (W+1) — one window of BM + 2W + 2 rows instead of nine BM-row tiles. The
+// gather kernel above stages 9 x (BM + BN) rows per 64-channel chunk and is bound by exactly that L2 -> LDS staging rate
+// (DESIGN.md section 5); here a chunk stages the window once plus nine BN-row weight tiles (0.57x the rows at 14x14 / 128x128).
+//   LDS: [window of HRI x 1 KiB][1 KiB with a zero row][2 weight stages of BN x 128 B]; same 128-byte swizzled rows.
+//   A fragment of tap (dy, dx) = halo rows shifted by dy*W + dx (the swizzle key follows the shifted row); a lane whose pixel
+//   has no (y+dy, x+dx) inside the image reads the zero row instead -> the border arithmetic of the gather kernel (zero
+//   contributions) without per-tap staging. Rows >= M read zeros for every tap (BatchNorm partials rely on that).
+//   Weight tiles: ring of 2, one tile per (chunk, tap) step. ONE window buffer, reloaded between chunks: a second buffer (next
+//   window arriving under the current chunk's taps) measured slower than the third block per CU the smaller footprint allows
+//   (14x14 x 256: 0.372 vs 0.363 ms, 7x7 x 512: 0.304 vs 0.277 ms; the gather kernel: 0.440 / 0.369).
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, BM / WM > 64 ? 2 : 1) void conv3x3_halo_bf16_kernel(const GatherGemmParams p, const int hri) {
+  static_assert(WM * WN == 4 && BN / WN == 64 && (BM / WM == 64 || BM / WM == 128), "four waves, 64 or 128 rows x 64 columns each");
+  constexpr int TM = BM / WM / 32, TN = 2;
+  constexpr int BJ = BN / 32;                        // weight DMA instructions per wave per tile
+  constexpr int WSTAGE = BN * 128;                   // bytes
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Bb = reinterpret_cast<const char*>(p.B);
+  const int W = p.Wi, HW = p.Hi * p.Wi;
+  const int halo_bytes = hri * 1024;
+  unsigned char* zrow = smem + halo_bytes;                            // 128 zero bytes (1 KiB reserved)
+  unsigned char* wring = zrow + 1024;
+  if (tid < 8) *reinterpret_cast<uint4*>(zrow + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  const int srow = lane >> 3, pslot = lane & 7;
+  const long long hb = (long long)m0 - (W + 1);                        // pixel staged in halo row 0
+  const char* zline = reinterpret_cast<const char*>(g_zero_bytes) + pslot * 16;
+  // DMA instruction i of the window of chunk c: halo rows 8i .. 8i+7
+  auto issue_halo = [&](int c, int i) __attribute__((always_inline)) {
+    const int hr = 8 * i + srow;
+    const long long px = hb + hr;
+    const bool in = px >= 0 && px < (long long)p.M;
+    const long long pc = in ? px : 0;
+    const char* src = Ab + (pc * p.Ci) * 2 + c * 128 + ((pslot ^ ((hr >> 1) & 7)) * 16);
+    dma16(sel_ptr(src, zline, in), smem + i * 1024);
+  };
+  const char* bptr[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int r = wave * (BN / 4) + j * 8 + srow;
+    const int n = min(n0 + r, p.Nc - 1);
+    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ ((r >> 1) & 7)) * 16;
+  }
+  auto issue_w = [&](int c, int pack, int stage) __attribute__((always_inline)) {
+    const int wt = pack >> 16;
+    unsigned char* lb = wring + stage * WSTAGE + wave * (BN / 4) * 128;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) dma16(bptr[j] + ((long long)wt * p.Ci) * 2 + c * 128, lb + j * 1024);
+  };
+
+  // per-lane rows of the two A row tiles: halo row of the centre tap and a 9-bit validity mask (bit = tap position in p.tap[])
+  const int lrow = lane & 31, lh = lane >> 5;
+  int crow[TM];
+  unsigned vmask[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * (BM / WM) + t * 32 + lrow;
+    crow[t] = r + W + 1;
+    const int m = m0 + r;
+    unsigned v = 0;
+    if (m < p.M) {
+      const int rem = m % HW;
+      const int y = rem / W, x = rem - y * W;
+      for (int k = 0; k < 9; ++k) {
+        const int pk = p.tap[k];
+        const int dy = (pk << 24) >> 24, dx = (pk << 16) >> 24;
+        if ((unsigned)(y + dy) < (unsigned)p.Hi && (unsigned)(x + dx) < (unsigned)W) v |= 1u << k;
+      }
+    }
+    vmask[t] = v;
+  }
+  const int zoff = (int)(zrow - smem);
+  int goffb[4];
+  const int xrb = (lrow >> 1) & 7;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) goffb[g] = ((2 * g + lh) ^ xrb) * 16;
+  const unsigned char* fragB0 = wring + (wn * 64 + lrow) * 128;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nc = p.Ci >> 6;
+  // prologue: window of chunk 0, weight tile (0, tap 0)
+  for (int i = wave; i < hri; i += 4) issue_halo(0, i);
+  issue_w(0, p.tap[0], 0);
+  int stage = 0;
+  for (int c = 0; c < nc; ++c) {
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool last_tap = k == 8;     // next weight tile
+      if (!last_tap) issue_w(c, p.tap[k + 1], stage ^ 1);
+      else if (c + 1 < nc) issue_w(c + 1, p.tap[0], stage ^ 1);
+      const int pk = p.tap[k];
+      const int shift = ((pk << 24) >> 24) * W + ((pk << 16) >> 24);
+      int abase[TM], akey[TM];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const bool ok = (vmask[t] >> k) & 1u;
+        const int rv = crow[t] + shift;
+        abase[t] = ok ? rv * 128 : zoff;
+        akey[t] = ok ? ((rv >> 1) & 7) : 0;
+      }
+      const unsigned char* fb = fragB0 + stage * WSTAGE;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const bf16x8*>(smem + abase[t] + (((2 * g + lh) ^ akey[t]) * 16));
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * 128 + goffb[g]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      }
+      stage ^= 1;
+    }
+    if (c + 1 < nc) {
+      __syncthreads();                                 // every wave is done with this chunk's window
+      for (int i = wave; i < hri; i += 4) issue_halo(c + 1, i);
+    }
+  }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
+  // a 256 x 128 tile writes one partial row per 128-row half (the partial geometry of the 128-row tiles)
+  if (EPI & EPI_STATS) gg_stats<BM, BN, WM, WN, (BM == 256 && BN == 128)>(p, acc, reinterpret_cast<float*>(smem), n0, mt);
+  gg_store_bf16<BM, BN, WM, WN, EPI, 40960 / 4>(p, acc, reinterpret_cast<float*>(smem), m0, n0);
+}
+
+// LDS bytes of the halo kernel for a tile of BM pixels at image width W
+static inline int halo_lds_bytes(int BM, int BN, int W) {
+  const int hri = ceil_div(BM + 2 * W + 2, 8);
+  const int b = hri * 1024 + 1024 + 2 * BN * 128;
+  return b < 40960 ? 40960 : b;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+static int halo_launch_one(const GatherGemmParams& p, hipStream_t s) {
+  const int hri = ceil_div(BM + 2 * p.Wi + 2, 8);
+  const int lds = halo_lds_bytes(BM, BN, p.Wi);
+  auto kern = conv3x3_halo_bf16_kernel<BM, BN, WM, WN, EPI>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_last_error("conv3x3_halo(bf16): cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_lds = lds;
+  }
+  const int grid = ceil_div(p.M, BM) * ceil_div(p.Nc, BN);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, hri);
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int halo_launch(const GatherGemmParams& p, hipStream_t s) {
+  switch (p.flags) {
+    case 0: return halo_launch_one<BM, BN, WM, WN, 0>(p, s);
+    case EPI_STATS: return halo_launch_one<BM, BN, WM, WN, EPI_STATS>(p, s);
+    case EPI_ACCUM: return halo_launch_one<BM, BN, WM, WN, EPI_ACCUM>(p, s);
+    case EPI_MASKED_ADD: return halo_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD>(p, s);
+    default: set_last_error("conv3x3_halo(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
+  }
+}
+
+// 3x3 stride-1 launches go through the halo kernel; wide launches with enough rows use the 256 x 128 tile (0.55x the staged rows
+// of the 128 x 128 halo tile again: 14x14 x 256 at 1280 frames 0.317 ms against 0.380, the gather kernel 0.450).
+// R3M_BF16_HALO=0: gather kernel; =2: 128-row tiles only; =4: 256-row tile whatever M (tests)
+static int gg16_halo() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_BF16_HALO"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+static bool halo_eligible(const GatherGemmParams& p) {
+  if (p.ntaps != 9 || p.simple_rows || p.is != 1 || p.os != 1 || p.ooy != 0 || p.oox != 0) return false;
+  if (p.Hg != p.Hi || p.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || (p.Ci & 63) || (p.Nc & 7)) return false;
+  if (!(p.Nc % 128 == 0 || p.Nc == 64)) return false;
+  if (p.flags != 0 && p.flags != EPI_STATS && p.flags != EPI_ACCUM && p.flags != EPI_MASKED_ADD) return false;
+  for (int k = 0; k < 9; ++k)
+    if (p.dy[k] < -1 || p.dy[k] > 1 || p.dx[k] < -1 || p.dx[k] > 1) return false;
+  return true;
+}
+
+// tile rows of the halo launch (0: the window does not fit the LDS -> gather kernel)
+static int halo_tile_rows(const GatherGemmParams& p) {
+  if (p.Nc == 64) return halo_lds_bytes(256, 64, p.Wi) <= 160 * 1024 ? 256 : 0;
+  const int h = gg16_halo();
+  const int min_m = h == 4 ? 0 : 65536;      // 7x7 x 512 at 1280 frames (M = 62720) measured the same either way
+  if (h != 2 && p.M >= min_m && halo_lds_bytes(256, 128, p.Wi) <= 80 * 1024) return 256;
+  return halo_lds_bytes(128, 128, p.Wi) <= 160 * 1024 ? 128 : 0;
+}
+
+static int launch_halo(const GatherGemmParams& p, int rows, hipStream_t s) {
+  if (p.Nc == 64) return halo_launch<256, 64, 4, 1>(p, s);
+  return rows == 256 ? halo_launch<256, 128, 2, 2>(p, s) : halo_launch<128, 128, 2, 2>(p, s);
+}
+
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK>
@@ -311,6 +530,15 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   const bool ring = gg16_ring_min() > 0 && nk >= gg16_ring_min();
   const bool w8 = gg16_ring_min() < 0;       // experiment: 8 waves, 2 stages (2 blocks/CU = 16 waves/CU)
   int rc;
+  const int halo_rows = (gg16_halo() && halo_eligible(p)) ? halo_tile_rows(p) : 0;
+  if (halo_rows) {
+    prof_begin(gg_wide(p.Nc) ? KC_GEMM_WIDE : KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    rc = launch_halo(p, halo_rows, s);
+    prof_bytes(gather_gemm_alg_bytes(p, 2));
+    prof_end(s);
+    if (rc) return rc;
+    return check_launch("conv3x3_halo_bf16");
+  }
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
