@@ -762,6 +762,189 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
     }
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 weight gradient with ALL NINE TAPS per block: dW[co, tap, ci] = sum_m dY[m, co] * X[m + shift(tap), ci].
+// The per-tap kernel above stages a dY tile and an X tile for every tap (18 rows per contraction row); here a K step of 64
+// pixels stages the dY rows once and ONE X window of 64 + 2W + 2 rows that all taps read at their row shift (3.9 rows per
+// contraction row at 56x56, 2.5 at 14x14). Block = one 64 (co) x 64 (ci) tile x 9 taps, four waves of 32 x 32 x 9 (144
+// accumulator registers per lane), split-K partials as before.
+// The border rule varies ALONG the contraction (a pixel at x = 0 has no left neighbour: dx = -1 drops pixels with x = 0, dx = +1
+// those with x = W-1, dy = -1 / +1 those with y = 0 / H-1; rows of other frames inside the window are exactly those the dy masks
+// remove), so it cannot be a row redirect as in the forward halo kernel — the X fragments are masked in registers. A wave issues
+// one instruction per 4 cycles whatever its kind, so the budget is ~135 instructions per k group (9 MFMAs): general per-element
+// masks (8-bit drop masks expanded to 16-bit lanes: 550 instructions, even on the scalar unit) ran at 390 TFLOP/s. Restricted to
+// image widths that are multiples of 8 the masks collapse to "element 0", "element 7" and "all" per lane half (see below).
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_bf16_kernel(const WgradParams p, const int xri) {
+  constexpr int BK = 64;
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int stage_bytes = BK * 128 + xri * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bx = lid % p.gx, by = lid / p.gx;          // by = split index: consecutive logical blocks read the same rows
+  const int tn_ = bx % p.tilesN, tm_ = bx / p.tilesN;
+  const int co0 = tm_ * 64, ci0 = tn_ * 64;
+  const int ms = by * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  const int W = p.Wi, H = p.Hi;
+  const char* dYb = reinterpret_cast<const char*>(p.dY);
+  const char* Xb = reinterpret_cast<const char*>(p.X);
+
+  // DMA lane -> (k row within the instruction, physical 16-byte slot); logical slot = physical ^ 4 * key, key = (row >> 1) & 1
+  const int d_k = lane >> 3, d_ps = lane & 7;
+  const int d_key = (d_k >> 1) & 1;
+  const int a_cb = (co0 + (d_ps ^ (4 * d_key)) * 8) * 2;
+  const int b_cb = (ci0 + (d_ps ^ (4 * d_key)) * 8) * 2;
+  const char* zl = reinterpret_cast<const char*>(g_zero_bytes) + (lane & 15) * 16;
+  int a_m[2];
+  const char* a_ptr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    a_m[j] = ms + wave * 16 + j * 8 + d_k;
+    a_ptr[j] = dYb + (long long)a_m[j] * p.Co * 2 + a_cb;
+  }
+  const long long a_step = (long long)BK * p.Co * 2;
+  auto issue = [&](int stage, int mk) __attribute__((always_inline)) {
+    unsigned char* st = smem + stage * stage_bytes;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      dma16(sel_ptr(a_ptr[j], zl, a_m[j] < me), st + (wave * 16 + j * 8) * 128);
+      a_m[j] += BK;
+      a_ptr[j] += a_step;
+    }
+    for (int i = wave; i < xri; i += 4) {
+      const long long q = (long long)mk - (W + 1) + 8 * i + d_k;
+      const bool in = q >= 0 && q < (long long)p.M;
+      const char* src = Xb + ((in ? q : 0) * p.Ci) * 2 + b_cb;
+      dma16(sel_ptr(src, zl, in), st + BK * 128 + i * 1024);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  // transpose-read addressing (see wgrad_bf16_kernel): lane -> k row 8*(lane>>5) + (q>>2), 4 channels of its 32-channel group
+  const int q16 = lane & 15;
+  const int frow = 8 * (lane >> 5) + (q16 >> 2);
+  const int fcol = (16 * ((lane >> 4) & 1) + 4 * (q16 & 3)) * 2;
+  const int fa_off = frow * 128 + ((wm ^ ((frow >> 1) & 1)) * 64) + fcol;
+  int fb_off[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int rowb = frow + (W + 1) + (t / 3 - 1) * W + (t % 3 - 1);       // window row of this lane's first k row at tap t
+    fb_off[t] = BK * 128 + rowb * 128 + ((wn ^ ((rowb >> 1) & 1)) * 64) + fcol;
+  }
+  auto tr_read = [&](const unsigned char* ptr) __attribute__((always_inline)) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  };
+  auto frag = [&](const unsigned char* base, int sidx) __attribute__((always_inline)) {
+    const s16x4 lo = tr_read(base + (16 * sidx) * 128);
+    const s16x4 hi = tr_read(base + (16 * sidx + 4) * 128);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  // image coordinates of the first pixel of the K step (pixel ms + kt*64): block-uniform, kept in scalar registers
+  const int invW = 65536 / W + 1;                       // (v * invW) >> 16 == v / W for v < 4096
+  int ox, oy;
+  {
+    const int row = ms / W;
+    ox = __builtin_amdgcn_readfirstlane(ms - row * W);
+    oy = __builtin_amdgcn_readfirstlane(row % H);
+  }
+  const int adv_q = BK / W, adv_r = BK - adv_q * W;
+  const bool hi_half = lane >= 32;
+
+  const int nk = (me - ms + BK - 1) / BK;
+  if (nk > 0) issue(0, ms);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(cur ^ 1, ms + (kt + 1) * BK);
+    const unsigned char* st = smem + cur * stage_bytes;
+    static_for<4>([&](auto s_c) __attribute__((always_inline)) {
+      constexpr int sidx = decltype(s_c)::value;
+      const bf16x8 a = frag(st + fa_off, sidx);
+      // Border masks. W and H*W are multiples of 8 (launcher) and K steps start at multiples of 64 pixels, so the 8 consecutive
+      // pixels a lane half holds never straddle an image row: x = 0 can only be its element 0, x = W-1 only its element 7, and
+      // the first / last image row covers the run entirely or not at all. Four flags per half on the scalar unit, four per-lane
+      // mask dwords, at most four ANDs per tap.
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      unsigned sL[2], sR[2], sT[2], sB[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int xs = ox + 16 * sidx + 8 * h, ys = oy;
+        const int qd = (xs * invW) >> 16;
+        xs -= qd * W;
+        ys += qd;
+        ys = ys >= H ? ys - H : ys;
+        ys = ys >= H ? ys - H : ys;
+        sL[h] = xs == 0 ? 0xffff0000u : 0xffffffffu;          // drop element 0 (left neighbour of x = 0)
+        sR[h] = xs + 8 == W ? 0x0000ffffu : 0xffffffffu;      // drop element 7 (right neighbour of x = W-1)
+        sT[h] = ys == 0 ? 0u : 0xffffffffu;                   // first image row: nothing above
+        sB[h] = ys == H - 1 ? 0u : 0xffffffffu;               // last image row: nothing below
+      }
+      const unsigned mL = hi_half ? sL[1] : sL[0], mR = hi_half ? sR[1] : sR[0];
+      const unsigned mT = hi_half ? sT[1] : sT[0], mB = hi_half ? sB[1] : sB[0];
+      static_for<9>([&](auto t_c) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int kh = t / 3, kw = t % 3;
+        u32x4_t u = __builtin_bit_cast(u32x4_t, frag(st + fb_off[t], sidx));
+        if constexpr (kh != 1) {
+          const unsigned my = kh == 0 ? mT : mB;
+          u[0] &= (kw == 0 ? (my & mL) : my);
+          u[1] &= my;
+          u[2] &= my;
+          u[3] &= (kw == 2 ? (my & mR) : my);
+        } else {
+          if constexpr (kw == 0) u[0] &= mL;
+          if constexpr (kw == 2) u[3] &= mR;
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, u), acc[t], 0, 0, 0);
+      });
+    });
+    // next K step: 64 pixels further
+    ox += adv_r;
+    oy += adv_q;
+    if (ox >= W) { ox -= W; ++oy; }
+    while (oy >= H) oy -= H;
+  }
+
+  float* out = p.out + (long long)by * p.Co * 9 * p.Ci;
+  const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int ci = ci0 + wn * 32 + lrow;
+      out[((long long)co * 9 + t) * p.Ci + ci] = acc[t][r];
+    }
+}
+
+// 3x3 stride-1 weight gradients at image widths that are multiples of 8 go through the all-taps kernel (56x56 x 64 channels at
+// 1280 frames: 0.834 -> 0.470 ms; ResNet-50 step -1.1 %, ResNet-34 -4.2 %). R3M_WG16_HALO=0: per-tap kernel
+static int wg16_halo() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("R3M_WG16_HALO"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+static inline int wgrad_halo_lds_bytes(int W) { return 2 * (64 * 128 + ceil_div(64 + 2 * W + 2, 8) * 1024); }
+
+static bool wgrad_halo_eligible(const WgradParams& p) {
+  // widths that are multiples of 8 (56 x 56: the 64-channel layers, where the per-tap kernel is furthest from its roof)
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi && (p.Wi & 7) == 0 && p.Wi >= 8 &&
+         p.Hi >= 2 && p.Wi <= 1024 && wgrad_halo_lds_bytes(p.Wi) <= 80 * 1024;
+}
+
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
 
 // split-K factor: enough blocks to fill the chip ~4 (wide) / ~10 (narrow) times, rows per split a multiple of 64
@@ -770,7 +953,9 @@ int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   const int tiles = wide ? (Co / 128) * (Ci / 128) * T : ceil_div(Co, 64) * ceil_div(Ci, 64) * T;
   static int tgt = -1;     // R3M_WG16_BLOCKS: target block count of the 128x128 launches (experiments)
   if (tgt < 0) { const char* e = getenv("R3M_WG16_BLOCKS"); tgt = e ? atoi(e) : 0; }
-  int split = (wide ? (tgt > 0 ? tgt : 1024) : 2560) / (tiles > 0 ? tiles : 1);
+  // the all-taps kernel runs one block per (tile, split) for all nine taps: 512 splits of the 64-channel layers fill the chip
+  const int narrow_target = (T == 9 && wg16_halo()) ? 512 * 9 : 2560;
+  int split = (wide ? (tgt > 0 ? tgt : 1024) : narrow_target) / (tiles > 0 ? tiles : 1);
   const int max_split = ceil_div(M, 256);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -795,6 +980,23 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
     static int xc = -1;
     if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
     p.xcd = xc;
+  }
+  if (wg16_halo() && wgrad_halo_eligible(p)) {
+    p.tilesN = p.Ci / 64;
+    p.gx = (p.Co / 64) * p.tilesN;
+    const int lds = wgrad_halo_lds_bytes(p.Wi);
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_halo_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        set_last_error("wgrad3x3_halo(bf16): cannot reserve %d bytes of LDS", lds);
+        return 1;
+      }
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(wgrad3x3_halo_bf16_kernel, dim3(p.gx * splitK), dim3(256), lds, s, p, ceil_div(64 + 2 * p.Wi + 2, 8));
+    prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
+    prof_end(s);
+    return check_launch("wgrad3x3_halo_bf16");
   }
   const dim3 grid(p.gx * splitK);
   // K steps of 32 rows for the 128x128 tile (32 KB of stages instead of 64: -16 % measured over ResNet-50), 64 rows for the

@@ -36,6 +36,7 @@ CONV_CASES = [
     (2, 56, 64, 128, 3, 2, 1), (2, 56, 64, 128, 1, 2, 0), (2, 28, 128, 256, 3, 2, 1), (3, 14, 256, 512, 3, 2, 1),
     (3, 9, 64, 64, 3, 1, 1), (1, 11, 64, 192, 3, 2, 1), (7, 5, 192, 64, 1, 1, 0),
     (84, 28, 128, 128, 3, 1, 1),      # M = 65 856 rows: the 256 x 128 halo tile (wide 3x3 stride-1 launches with M >= 65 536)
+    (3, 8, 64, 128, 3, 1, 1), (5, 16, 128, 64, 3, 1, 1),   # image widths that are multiples of 8: the all-taps weight-gradient kernel
 ]
 
 
