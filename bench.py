@@ -106,7 +106,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU (WORLD_SIZE={world}); launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the
+    # gradient all-reduces are issued — also with one rank, where a mean over one rank is the identity: `torchrun
+    # --nproc-per-node 1 bench.py --gpus 1` therefore executes the same collective / barrier / max-over-ranks code that N = 8 runs.
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -120,7 +124,7 @@ def main():
     model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=args.langweight, tcnweight=1.0,
                 l2dist=True, bs=B, precision=args.precision)
     model = model.to(dev)
-    net = make_network_wrapper(model)
+    net = make_network_wrapper(model, force=use_dist)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     if args.doaug == "none":
         frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
@@ -137,7 +141,7 @@ def main():
     trainer = Trainer(eval_freq=10 ** 9)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,7 +172,7 @@ def main():
         t_pw = time.perf_counter()
         while True:
             go = time.perf_counter() - t_pw < args.prewarm_seconds
-            if world > 1:                               # every rank must run the same number of steps (collectives inside)
+            if use_dist:                                # every rank must run the same number of steps (collectives inside)
                 flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 go = bool(flag.item())
@@ -179,6 +183,7 @@ def main():
             prewarm_steps += 1
     for i in range(args.warmup):
         trainer.update(net, (get_frames(), langs), i)
+    total_steps = prewarm_steps + args.warmup + args.steps
     L.r3m_profile_enable(0 if args.no_kernel_timing else 1)
     if args.launch_csv and rank == 0:
         _lib.check(L.r3m_profile_dump_to(args.launch_csv.encode()), "profile_dump_to")
@@ -192,7 +197,7 @@ def main():
     _lib.check(L.r3m_profile_collect(ms, launches, flops), "profile_collect")
     L.r3m_profile_enable(0)
     L.r3m_profile_dump_to(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -213,13 +218,32 @@ def main():
         ach = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         bf16 = args.precision == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest_bf16.json" if bf16 else "pmc_latest.json")
+        # HBM bytes per launch of the dominant class come from the PMC passes (rocprofv3 --pmc cannot run inside this
+        # process): NOT measured in this run — read from the committed summary of the last counter run, and labelled as such.
+        traffic, traffic_source = None, None
+        pmc_name = "pmc_latest_bf16.json" if bf16 else "pmc_latest.json"
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("dominant_kernel_hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))
+                traffic = pj.get("dominant_kernel_hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{pmc_name} <- {pj.get('source')} (separate rocprofv3 --pmc passes of an earlier run of "
+                                  f"this command; FETCH_SIZE x2 + WRITE_SIZE, KiB units; not measured live)")
             except Exception:
                 traffic = None
+        # which BASELINE config this run IS (never a label for work that is not executed)
+        if bf16:
+            cfg_label = ("BASELINE configs[4]" if args.size == 34 and args.doaug == "rctraj" else
+                         "BASELINE configs[2]" if args.size == 50 and args.langweight > 0 else
+                         f"bf16 variant of the ResNet-{args.size} step")
+        elif args.size == 50 and args.langweight > 0:
+            cfg_label = "BASELINE configs[3] (full R3M loss: LP + TCN + language InfoNCE through the reward head)"
+        elif args.size == 50:
+            cfg_label = "BASELINE configs[1]"
+        else:
+            cfg_label = f"fp32 ResNet-{args.size} variant of BASELINE configs[1]"
+        if world > 1:
+            cfg_label += f", replicated on {world} GPUs (weak scaling, RCCL gradient mean overlapped with backward)"
         out = {
             "metric": "encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU" if args.size == 50 and B == 256 else
                       f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2 bs={B}/GPU",
@@ -227,13 +251,16 @@ def main():
             "prewarm_steps": prewarm_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{(4 if args.size == 34 else 2) if bf16 else (3 if world > 1 else 1)}]: ResNet-{args.size} R3M step (encoder fwd + LP/TCN loss + bwd + Adam), "
+            "config": {"workload": f"{cfg_label}: ResNet-{args.size} R3M step (encoder fwd + LP/TCN{'/language' if args.langweight > 0 else ''} loss + bwd + Adam), "
                                    f"{'bf16 activations / bf16 MFMA, fp32 master weights + statistics + Adam' if bf16 else 'fp32'}, "
                                    f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist doaug={args.doaug}",
                        "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
+                       "collectives": (f"rccl all_reduce(AVG), {net.sync.launched / max(1, total_steps):.1f} per step"
+                                       + (" (one-rank group: identity, issued to exercise the path)" if world == 1 else ""))
+                                      if use_dist else "none (single process)",
                        "final_full_loss": metrics["full_loss"]},
             "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
                          "algorithmic_gflop_per_launch": round(flops[dom] / max(1, launches[dom]) / 1e9, 3),
                          "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[args.size] / 1e3 / peak, 4),
@@ -246,7 +273,7 @@ def main():
             ach_bw = bytes_k[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
             mf = out["roofline"]
             out["roofline"] = {"bound": "hbm", "kernel": KCLASS[dom], "achieved": round(ach_bw, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(ach_bw / PEAK_HBM_GBS, 4), "traffic": traffic,
+                               "frac": round(ach_bw / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                                "avg_launch_ms": mf["avg_launch_ms"],
                                "algorithmic_mbytes_per_launch": round(bytes_k[dom] / max(1, launches[dom]) / 1e6, 2),
                                "whole_step_frac": round(fps / world * MB_PER_FRAME_BF16[args.size] / 1e3 / PEAK_HBM_GBS, 4),
@@ -261,7 +288,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_clips)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

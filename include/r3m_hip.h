@@ -183,6 +183,17 @@ int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, 
                         size_t workspace_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream);
 int r3m_langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* workspace,
                          size_t workspace_bytes, int B, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream);
+/* ONE differentiable evaluation score[R] = G(e0[R,D], eg[R,D], le[R,lang_dim]) — the reference's own calling form
+ * (R3M.get_reward r3m/models/models_r3m.py:78-81 -> LanguageReward.forward models_language.py:53-55, called 15x with autograd
+ * by r3m/trainer.py:72-92). forward leaves the activations in `workspace` (r3m_langrew_call_workspace_bytes(R, ...));
+ * backward consumes them, writes parameter gradients (= or +=, flat layout as above) and WRITES the input gradients
+ * de0 / deg [R,D] and dle [R,lang_dim] (each may be NULL). */
+size_t r3m_langrew_call_workspace_bytes(int R, int D, int hidden, int lang_dim);
+int r3m_langrew_call_forward(const float* e0, const float* eg, const float* le, const float* params, float* score, void* workspace,
+                             size_t workspace_bytes, int R, int D, int hidden, int lang_dim, r3m_stream_t stream);
+int r3m_langrew_call_backward(const float* dscore, const float* params, float* grads, float* de0, float* deg, float* dle,
+                              void* workspace, size_t workspace_bytes, int R, int D, int hidden, int lang_dim, int accumulate,
+                              r3m_stream_t stream);
 
 /* ---------------- objective (r3m/trainer.py:39-152, R3M.sim models_r3m.py:102-107) ----------------------------
  * alle [B,5,D] (e0, eg, es0, es1, es2 per clip); perm/iperm [6][B] int32: the reference's torch.randperm draws in

@@ -59,3 +59,37 @@ def resnet_state_dict(named_shapes, tag="w"):
         else:
             out[key] = uniform(tag + key, shape, -0.2, 0.2)
     return out
+
+
+def smooth_frames(name, shape, grid=7):
+    """uint8-valued LOW-FREQUENCY frames [N,3,H,W] (float32 0..255): a coarse random colour grid per frame, bilinearly
+    upsampled (half-pixel centres) and floored. On i.i.d.-noise frames every frame looks alike to a deep network and the
+    bf16-activation arithmetic is ill-conditioned (tests/test_gpu_bf16.py); these frames differ from each other at the
+    scales the network sees."""
+    n, c, h, w = shape
+    coarse = uniform(name, (n, c, grid, grid), 0.0, 255.0).astype(np.float64)
+
+    def axis(size):
+        src = np.clip((np.arange(size) + 0.5) * (grid / size) - 0.5, 0.0, None)
+        i0 = np.minimum(src.astype(np.int64), grid - 1)
+        i1 = np.minimum(i0 + 1, grid - 1)
+        return i0, i1, src - i0
+
+    y0, y1, fy = axis(h)
+    x0, x1, fx = axis(w)
+    rows = coarse[:, :, y0, :] * (1.0 - fy)[None, None, :, None] + coarse[:, :, y1, :] * fy[None, None, :, None]
+    img = rows[:, :, :, x0] * (1.0 - fx) + rows[:, :, :, x1] * fx
+    return np.clip(np.floor(img), 0, 255).astype(np.float32)
+
+
+def resnet_state_dict_small_residual(named_shapes, size, scale=0.1, tag="w"):
+    """resnet_state_dict with the gamma of every block's LAST BatchNorm scaled by `scale` (small residual branches, as in a
+    zero-init-residual / trained network): the state in which the bf16-activation ResNet-50 is well conditioned in BOTH
+    BatchNorm modes (tools/experiments/bf16_conditioning.py: gradient cosine bf16-vs-exact 0.997 with batch statistics,
+    against 0.10-0.38 for the plain states)."""
+    out = resnet_state_dict(named_shapes, tag)
+    last = "bn3.weight" if size == 50 else "bn2.weight"
+    for key in out:
+        if key.startswith("layer") and key.endswith(last):
+            out[key] = (out[key] * np.float32(scale)).astype(np.float32)
+    return out

@@ -87,6 +87,9 @@ SIGNATURES = {
     "r3m_langrew_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "r3m_langrew_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_backward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_call_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "r3m_langrew_call_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_call_backward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_loss_workspace_bytes": (c_sz, [c_i]),
     "r3m_loss_tcn_lp": (c_i, [c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f]),
     "r3m_loss_lang_infonce": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_fl, c_f]),
@@ -129,9 +132,19 @@ def check(rc, what=""):
         raise RuntimeError(f"r3m_hip {what} failed (code {rc}): {last_error()}")
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """HIP stream handle torch is currently using on `device` (a torch.device / index; None = the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on(t):
+    """Context manager: make the device that owns tensor `t` current for the enclosed C-ABI calls. The library launches on
+    the stream it is handed and never calls hipSetDevice itself (include/r3m_hip.h: "device selected by the caller"), so
+    a module living on cuda:1 while cuda:0 is current must switch here — kernels, hipFuncSetAttribute and the profiling
+    events all bind to the current device."""
+    import torch
+    return torch.cuda.device(t.device)
 
 
 def ptr(t):

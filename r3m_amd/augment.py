@@ -50,8 +50,10 @@ def crop_resize(frames, boxes, frames_per_box, out_hw=(224, 224)):
     boxes = boxes.to(device=frames.device, dtype=torch.int32).contiguous()
     assert boxes.shape[0] * frames_per_box == N
     out = torch.empty((N, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=frames.device)
-    _lib.check(_lib.lib().r3m_crop_resize(frames.data_ptr(), 1 if frames.dtype == torch.uint8 else 0, boxes.data_ptr(), out.data_ptr(),
-                                          N, C, H, W, out_hw[0], out_hw[1], frames_per_box, _lib.stream_ptr()), "crop_resize")
+    with _lib.on(frames):
+        _lib.check(_lib.lib().r3m_crop_resize(frames.data_ptr(), 1 if frames.dtype == torch.uint8 else 0, boxes.data_ptr(),
+                                              out.data_ptr(), N, C, H, W, out_hw[0], out_hw[1], frames_per_box,
+                                              _lib.stream_ptr(frames.device)), "crop_resize")
     return out
 
 

@@ -310,8 +310,7 @@ static inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 // against 5.5-5.9 with four); the backward apply pass, which carries six coefficient vectors per thread, gains 15-20 % from
 // four items per thread in bf16, and a few % for C >= 512 in fp32. R3M_BN_ITEMS overrides.
 static inline int bn_span(int cv, int items) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("R3M_BN_ITEMS"); force = e ? atoi(e) : 0; }
+  const int force = R3M_ENV_INT("R3M_BN_ITEMS", 0);
   if (force > 0) items = force;
   if (cv > 256 || 256 % cv != 0) items = 1;
   return 256 * items;

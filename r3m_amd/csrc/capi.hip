@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,8 +24,7 @@ void set_last_error(const char* fmt, ...) {
 
 // R3M_TRACE=1: name every launch on stderr and synchronise after it (localises a faulting kernel; debugging only)
 static int trace_mode() {
-  static int t = -1;
-  if (t < 0) { const char* e = getenv("R3M_TRACE"); t = (e && *e && *e != '0') ? 1 : 0; }
+  const int t = R3M_ENV_INT("R3M_TRACE", 0) != 0;
   return t;
 }
 
@@ -41,34 +43,59 @@ int check_launch(const char* what) {
   return 0;
 }
 
+int ensure_dyn_lds(DynLdsOptIn& cache, const void* fn, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { set_last_error("%s: hipGetDevice failed", what); return 1; }
+  if (bytes <= __atomic_load_n(&cache.bytes[dev], __ATOMIC_RELAXED)) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    set_last_error("%s: cannot reserve %d bytes of LDS", what, bytes);
+    return 1;
+  }
+  __atomic_store_n(&cache.bytes[dev], bytes, __ATOMIC_RELAXED);
+  return 0;
+}
+
 // ---- per-kernel-class event timing ----
-struct ProfEvent { hipEvent_t a, b; int kclass; double flops, bytes; int M, N, K, taps; };
-static bool g_prof_on = false;
-static std::vector<ProfEvent> g_prof_pool;
-static size_t g_prof_used = 0;
-static bool g_prof_open = false;
+// Module state behind ONE mutex ("no mutable globals beyond lazily-initialised, mutex-guarded module state"):
+// forward launches come from the caller's thread, backward launches from an autograd engine thread, collect() from the
+// benchmark's thread. A launch's begin / bytes / end triple runs on one thread; the slot it fills is thread-local between
+// begin and end, so two threads launching concurrently get two slots. The fast path (profiling off) is one relaxed load.
+struct ProfEvent { hipEvent_t a, b; int kclass; double flops, bytes; int M, N, K, taps; bool closed; };
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::deque<ProfEvent> g_prof_pool;        // deque: growing never moves a slot another thread is filling
+static size_t g_prof_used = 0;                   // guarded by g_prof_mu
+static thread_local ProfEvent* t_prof_open = nullptr;
 
 void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStream_t s) {
-  if (!g_prof_on) return;
-  if (g_prof_used == g_prof_pool.size()) {
-    ProfEvent e;
-    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-    g_prof_pool.push_back(e);
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  ProfEvent* e = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_used == g_prof_pool.size()) {
+      ProfEvent ne{};
+      if (hipEventCreate(&ne.a) != hipSuccess || hipEventCreate(&ne.b) != hipSuccess) return;
+      g_prof_pool.push_back(ne);
+    }
+    e = &g_prof_pool[g_prof_used++];
+    e->closed = false;
   }
-  ProfEvent& e = g_prof_pool[g_prof_used];
-  e.kclass = kclass; e.flops = flops; e.bytes = 0.0; e.M = M; e.N = N; e.K = K; e.taps = taps;
-  (void)hipEventRecord(e.a, s);
-  g_prof_open = true;
+  e->kclass = kclass; e->flops = flops; e->bytes = 0.0; e->M = M; e->N = N; e->K = K; e->taps = taps;
+  (void)hipEventRecord(e->a, s);
+  t_prof_open = e;
 }
 // algorithmic HBM bytes of the launch opened by prof_begin (operands read once + results written once)
 void prof_bytes(double bytes) {
-  if (g_prof_on && g_prof_open) g_prof_pool[g_prof_used].bytes = bytes;
+  if (t_prof_open) t_prof_open->bytes = bytes;
 }
 void prof_end(hipStream_t s) {
-  if (!g_prof_on || !g_prof_open) return;
-  (void)hipEventRecord(g_prof_pool[g_prof_used].b, s);
-  ++g_prof_used;
-  g_prof_open = false;
+  if (!t_prof_open) return;
+  (void)hipEventRecord(t_prof_open->b, s);
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    t_prof_open->closed = true;
+  }
+  t_prof_open = nullptr;
 }
 
 int debug_occupancy(int* out4);
@@ -118,6 +145,11 @@ int langrew_forward(const float* alle, const float* feats, const int* perm, cons
                     int D, int H, int LD, hipStream_t s);
 int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
                      int H, int LD, int accumulate, hipStream_t s);
+size_t langrew_call_ws_floats(int R, int D, int H, int LD);
+int langrew_call_forward(const float* e0, const float* eg, const float* le, const float* params, float* score, float* ws, int R,
+                         int D, int H, int LD, hipStream_t s);
+int langrew_call_backward(const float* dscore, const float* params, float* grads, float* de0, float* deg, float* dle, float* ws,
+                          int R, int D, int H, int LD, int accumulate, hipStream_t s);
 
 }  // namespace r3m
 
@@ -131,10 +163,16 @@ extern "C" {
 int r3m_abi_version(void) { return 1; }
 
 int r3m_debug_occupancy(int* out4) { return debug_occupancy(out4); }
-void r3m_profile_enable(int on) { g_prof_on = on != 0; if (!on) g_prof_used = 0; }
+void r3m_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on.store(on != 0, std::memory_order_relaxed);
+  if (!on) g_prof_used = 0;
+}
 // optional: every launch since the last collect as CSV rows (class,M,N,K,taps,ms,gflop) into a host file
-static FILE* g_prof_dump = nullptr;
+static FILE* g_prof_dump = nullptr;              // guarded by g_prof_mu
+static double g_prof_bytes[KC_COUNT];            // guarded by g_prof_mu
 int r3m_profile_dump_to(const char* path) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof_dump) { fclose(g_prof_dump); g_prof_dump = nullptr; }
   if (path && *path) {
     g_prof_dump = fopen(path, "w");
@@ -143,15 +181,17 @@ int r3m_profile_dump_to(const char* path) {
   }
   return 0;
 }
-static double g_prof_bytes[KC_COUNT];
 int r3m_profile_collect_bytes(double* bytes) {   // algorithmic bytes per class of the launches seen by the LAST collect()
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int k = 0; k < KC_COUNT; ++k) bytes[k] = g_prof_bytes[k];
   return 0;
 }
 int r3m_profile_collect(double* ms, long long* launches, double* flops) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; flops[k] = 0.0; g_prof_bytes[k] = 0.0; }
   for (size_t i = 0; i < g_prof_used; ++i) {
     ProfEvent& e = g_prof_pool[i];
+    if (!e.closed) continue;                       // a launch still between begin and end on another thread
     if (hipEventSynchronize(e.b) != hipSuccess) { set_last_error("profile_collect: event sync failed"); return 1; }
     float t = 0.f;
     if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) { set_last_error("profile_collect: elapsed failed"); return 1; }
@@ -405,6 +445,23 @@ int r3m_langrew_backward(const float* dscore, const int* iperm, const float* par
   R3M_REQUIRE(dscore && iperm && params && grads && ws, "langrew_backward: null argument");
   R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_backward: workspace too small");
   return langrew_backward(dscore, iperm, params, grads, dalle, static_cast<float*>(ws), B, D, hidden, lang_dim, accumulate, S(stream));
+}
+
+size_t r3m_langrew_call_workspace_bytes(int R, int D, int hidden, int lang_dim) { return langrew_call_ws_floats(R, D, hidden, lang_dim) * 4; }
+int r3m_langrew_call_forward(const float* e0, const float* eg, const float* le, const float* params, float* score, void* ws,
+                             size_t ws_bytes, int R, int D, int hidden, int lang_dim, r3m_stream_t stream) {
+  R3M_REQUIRE(e0 && eg && le && params && score && ws, "langrew_call_forward: null argument");
+  R3M_REQUIRE(R > 0, "langrew_call_forward: R=%d rows", R);
+  R3M_REQUIRE(ws_bytes >= r3m_langrew_call_workspace_bytes(R, D, hidden, lang_dim), "langrew_call_forward: workspace too small");
+  return langrew_call_forward(e0, eg, le, params, score, static_cast<float*>(ws), R, D, hidden, lang_dim, S(stream));
+}
+int r3m_langrew_call_backward(const float* dscore, const float* params, float* grads, float* de0, float* deg, float* dle, void* ws,
+                              size_t ws_bytes, int R, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream) {
+  R3M_REQUIRE(dscore && params && grads && ws, "langrew_call_backward: null argument");
+  R3M_REQUIRE(R > 0, "langrew_call_backward: R=%d rows", R);
+  R3M_REQUIRE(ws_bytes >= r3m_langrew_call_workspace_bytes(R, D, hidden, lang_dim), "langrew_call_backward: workspace too small");
+  return langrew_call_backward(dscore, params, grads, de0, deg, dle, static_cast<float*>(ws), R, D, hidden, lang_dim, accumulate,
+                               S(stream));
 }
 
 int r3m_crop_resize(const void* frames, int frames_are_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,

@@ -5,6 +5,19 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// ---- experiment switches -------------------------------------------------------------------------------------
+// The SHIPPED library (r3m_amd/csrc/build.sh) has one code path per shape: it reads no environment variables and contains
+// none of the timing probes (some of which deliberately produce wrong results). Builds with -DR3M_PROBES
+// (tools/experiments/build_variants.sh) bring both back so the A/B measurements quoted in DESIGN.md can be repeated.
+#ifdef R3M_PROBES
+#include <cstdlib>
+#define R3M_ENV_INT(name, dflt) ([]() -> int { static const int v_ = []() { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }(); return v_; }())
+#define R3M_PROBE(p) ((p).debug)
+#else
+#define R3M_ENV_INT(name, dflt) (dflt)
+#define R3M_PROBE(p) 0
+#endif
+
 namespace r3m {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,6 +36,12 @@ int  check_launch(const char* what);  // hipGetLastError() -> 0 / code (+ messag
   } while (0)
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Opt-in for > 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), cached per call site AND per device:
+// function attributes belong to a device, and launches arrive from several host threads (forward: caller, backward: autograd
+// engine). The cache is a plain int per device — a racing pair of threads sets the same attribute twice, which is idempotent.
+struct DynLdsOptIn { int bytes[32] = {0}; };
+int ensure_dyn_lds(DynLdsOptIn& cache, const void* fn, int bytes, const char* what);
 
 // ---- epilogue flags of the gather-GEMM (conv fwd / dgrad / linear) ----
 enum : int {

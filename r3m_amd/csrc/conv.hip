@@ -132,17 +132,17 @@ __global__ __launch_bounds__(256) void gather_gemm_glds_kernel(const GatherGemmP
   int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
   if (nk > 0) issue_tile(pack_cur, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = (p.debug == 0) ? (kt & 1) : 0;       // timing probes read stage 0 only
-    if (p.debug != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of tile kt has landed
-    if (p.debug != 2) __syncthreads();                   // everyone's has; and everyone is done reading stage cur^1
-    if (kt + 1 < nk && p.debug != 1) {
+    const int cur = (R3M_PROBE(p) == 0) ? (kt & 1) : 0;       // timing probes read stage 0 only
+    if (R3M_PROBE(p) != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of tile kt has landed
+    if (R3M_PROBE(p) != 2) __syncthreads();                   // everyone's has; and everyone is done reading stage cur^1
+    if (kt + 1 < nk && R3M_PROBE(p) != 1) {
       if (++chunk_n == kpt) {
         chunk_n = 0;
         ++tap_n;
         pack_cur = pack_next;
         pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
       }
-      issue_tile(pack_cur, chunk_n, (p.debug == 0) ? (cur ^ 1) : 1);
+      issue_tile(pack_cur, chunk_n, (R3M_PROBE(p) == 0) ? (cur ^ 1) : 1);
     }
     const float* fa = fragA0 + cur * STAGE;
     const float* fb = fragB0 + cur * STAGE;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
     glds_issue<BM, BN, 0, 0>(pa, pb, smem, wave_s);               // tile 0
   }
   int pack_next = p.ntaps > 1 ? p.tap[1] : 0;
-  if (p.debug == 8) {   // clustered DMA issue (kept for A/B: R3M_GG_DEBUG=8)
+  if (R3M_PROBE(p) == 8) {   // clustered DMA issue (kept for A/B: R3M_GG_DEBUG=8)
     for (int pr = 0; pr < npairs; ++pr) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -539,8 +539,7 @@ int gather_gemm_grid_m(int M, int Nc) { return gg_wide(Nc) ? ceil_div(M, 128) : 
 
 // R3M_GG_GLDS: 2 (default) low-VALU direct-to-LDS kernel, 1 generic direct-to-LDS kernel, 0 register staging
 static int gg_use_glds() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_GG_GLDS"); v = e ? atoi(e) : 2; }
+  const int v = R3M_ENV_INT("R3M_GG_GLDS", 2);
   return v;
 }
 
@@ -575,8 +574,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
   if (p.dtype == DT_BF16) {
     {
-      static int dbg = -1;
-      if (dbg < 0) { const char* e = getenv("R3M_GG_DEBUG"); dbg = e ? atoi(e) : 0; }
+      const int dbg = R3M_ENV_INT("R3M_GG_DEBUG", 0);
       p.debug = dbg;   // timing probes only (wrong results when != 0)
     }
     R3M_REQUIRE(p.ntaps >= 0 && p.ntaps <= MAX_TAPS, "gather_gemm: ntaps=%d", p.ntaps);
@@ -593,8 +591,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
                   (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
               "gather_gemm: operands must be 16-byte aligned");
   {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("R3M_GG_DEBUG"); dbg = e ? atoi(e) : 0; }
+    const int dbg = R3M_ENV_INT("R3M_GG_DEBUG", 0);
     p.debug = dbg;   // timing probes only (wrong results when != 0)
   }
   for (int t = 0; t < p.ntaps; ++t)
@@ -1274,8 +1271,7 @@ int debug_occupancy(int* out4) {
 }
 
 static bool wg_use_glds() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_WG_GLDS"); v = (e && *e == '0') ? 0 : 1; }
+  const int v = R3M_ENV_INT("R3M_WG_GLDS", 1) != 0;
   return v == 1;
 }
 
@@ -1304,11 +1300,9 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
   R3M_REQUIRE(ceil_div(p.M, p.rows_per_split) == splitK, "wgrad: splitK=%d does not tile M=%d", splitK, p.M);
   const int T = p.KH * p.KW;
   {
-    static int il = -1;
-    if (il < 0) { const char* e = getenv("R3M_WG_INTERLEAVE"); il = e ? atoi(e) : 0; }
+    const int il = R3M_ENV_INT("R3M_WG_INTERLEAVE", 0);
     p.interleave = il;
-    static int xc = -1;
-    if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
+    const int xc = R3M_ENV_INT("R3M_WG_XCD", 1);
     p.xcd = xc;
   }
   const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * (p.Ci == 160 ? 147 : p.Ci);

@@ -137,8 +137,8 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
-      if ((p.debug & 8) && dx != 0) return;     // probe 8: stage the A tile of the centre-column taps only (bytes-per-flop what-if)
-      if ((p.debug & 16) && (dx != 0 || dy != 0)) return;   // probe 16: ... of the centre tap only
+      if ((R3M_PROBE(p) & 8) && dx != 0) return;     // probe 8: stage the A tile of the centre-column taps only (bytes-per-flop what-if)
+      if ((R3M_PROBE(p) & 16) && (dx != 0 || dy != 0)) return;   // probe 16: ... of the centre tap only
       const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
       const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
       const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
@@ -186,12 +186,12 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
     if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // everyone's have; and everyone is done reading ring slot istage
-    const bool more = NST > 1 && (kt + NST - 1 < nk) && !(p.debug & 2);   // probe 2: no DMA after the prologue
+    const bool more = NST > 1 && (kt + NST - 1 < nk) && !(R3M_PROBE(p) & 2);   // probe 2: no DMA after the prologue
     const unsigned char* fa = fragA0 + cstage * STAGE;
     const unsigned char* fb = fragB0 + cstage * STAGE;
     // all DMA pieces right after the barrier: with the 16x faster MFMA there is no issue cost worth hiding, and the earlier
     // the loads leave the sooner they land (+2..8 % over spreading them between the MFMA groups; probe 4 = spread)
-    const bool clustered = (p.debug & 4) == 0;
+    const bool clustered = (R3M_PROBE(p) & 4) == 0;
     if (more && clustered) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(istage, pc); });
     static_for<NG>([&](auto g_c) __attribute__((always_inline)) {
       constexpr int g = decltype(g_c)::value;
@@ -220,7 +220,7 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the stages
 
-  if (p.debug & 1) {   // probe 1: no epilogue (one store keeps the accumulators alive)
+  if (R3M_PROBE(p) & 1) {   // probe 1: no epilogue (one store keeps the accumulators alive)
     if (acc[0][0][0] + acc[TM - 1][TN - 1][3] == 123.456f) reinterpret_cast<float*>(p.out)[0] = 1.f;
     return;
   }
@@ -392,14 +392,8 @@ static int halo_launch_one(const GatherGemmParams& p, hipStream_t s) {
   const int hri = ceil_div(BM + 2 * p.Wi + 2, 8);
   const int lds = halo_lds_bytes(BM, BN, p.Wi);
   auto kern = conv3x3_halo_bf16_kernel<BM, BN, WM, WN, EPI>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      set_last_error("conv3x3_halo(bf16): cannot reserve %d bytes of LDS", lds);
-      return 1;
-    }
-    attr_lds = lds;
-  }
+  static DynLdsOptIn optin;
+  if (int e = ensure_dyn_lds(optin, reinterpret_cast<const void*>(kern), lds, "conv3x3_halo(bf16)")) return e;
   const int grid = ceil_div(p.M, BM) * ceil_div(p.Nc, BN);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p, hri);
   return 0;
@@ -420,8 +414,7 @@ static int halo_launch(const GatherGemmParams& p, hipStream_t s) {
 // of the 128 x 128 halo tile again: 14x14 x 256 at 1280 frames 0.317 ms against 0.380, the gather kernel 0.450).
 // R3M_BF16_HALO=0: gather kernel; =2: 128-row tiles only; =4: 256-row tile whatever M (tests)
 static int gg16_halo() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_HALO"); v = e ? atoi(e) : 1; }
+  const int v = R3M_ENV_INT("R3M_BF16_HALO", 1);
   return v;
 }
 
@@ -458,14 +451,8 @@ static int gg16_launch_one(const GatherGemmParams& p, int grid, hipStream_t s) {
   constexpr int tiles = NST * (BM + BN) * BK * 2;
   constexpr int lds = tiles > slab ? (tiles > slab32 ? tiles : slab32) : (slab > slab32 ? slab : slab32);
   auto kern = gather_gemm_bf16_kernel<BM, BN, WM, WN, EPI, NST, BK>;
-  static bool attr_set = false;     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      set_last_error("gather_gemm(bf16): cannot reserve %d bytes of LDS", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
+  static DynLdsOptIn optin;         // > 64 KiB of dynamic LDS needs the opt-in once per kernel (and device)
+  if (int e = ensure_dyn_lds(optin, reinterpret_cast<const void*>(kern), lds, "gather_gemm(bf16)")) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return 0;
 }
@@ -485,15 +472,13 @@ static int gg16_launch(const GatherGemmParams& p, int grid, hipStream_t s) {
 // ResNet-50 shapes it LOSES 20-30 % to two co-resident 4-wave blocks (one block per CU leaves its prologue and epilogue
 // uncovered, and the 2 x 4 wave layout reads 1.5x the LDS bytes per tile). Kept for experiments.
 static int gg16_ring_min() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_RING"); v = e ? atoi(e) : 0; }
+  const int v = R3M_ENV_INT("R3M_BF16_RING", 0);
   return v;
 }
 
 // R3M_BF16_SINGLE=0 disables the single-stage configuration of one-K-tile launches
 static bool gg16_single() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_SINGLE"); v = e ? atoi(e) : 1; }
+  const int v = R3M_ENV_INT("R3M_BF16_SINGLE", 1);
   return v != 0;
 }
 
@@ -503,8 +488,7 @@ static bool gg16_single() {
 // dominates: K >= 4 N, i.e. the 3x3 convs and the contracting 1x1 convs (per-shape table: tools/experiments/gpu_bk32b.sh).
 // The 256x64 tile's 3x3 launches are the exception (measured -4 % with 32). R3M_BF16_BK=32 / 64 forces one width.
 static bool gg16_bk32(const GatherGemmParams& p, bool wide) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_BK"); v = e ? atoi(e) : 0; }
+  const int v = R3M_ENV_INT("R3M_BF16_BK", 0);
   if (v == 32) return true;
   if (v == 64) return false;
   const long long ktot = (long long)p.ntaps * p.Ci;
@@ -517,8 +501,7 @@ static bool gg16_bk32(const GatherGemmParams& p, bool wide) {
 // ~35 % of the MFMA peak; 128 x 64 per wave needs 0.75x the fragment bytes per flop. R3M_BF16_BIG=0 disables, =64 uses 64-wide
 // K tiles (96 KB ring, one block per CU) instead of 32-wide (48 KB, two blocks).
 static int gg16_big() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_BF16_BIG"); v = e ? atoi(e) : 0; }
+  const int v = R3M_ENV_INT("R3M_BF16_BIG", 0);
   return v;
 }
 
@@ -884,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_bf16_kernel(const WgradP
         const int qd = (xs * invW) >> 16;
         xs -= qd * W;
         ys += qd;
-        ys = ys >= H ? ys - H : ys;
+        ys = ys >= H ? ys - H : ys;     // qd <= 7 (W >= 8, 64-pixel K steps) and H >= 4 (launcher): two wraps cover oy + qd < 3 H
         ys = ys >= H ? ys - H : ys;
         sL[h] = xs == 0 ? 0xffff0000u : 0xffffffffu;          // drop element 0 (left neighbour of x = 0)
         sR[h] = xs + 8 == W ? 0x0000ffffu : 0xffffffffu;      // drop element 7 (right neighbour of x = W-1)
@@ -932,8 +915,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_bf16_kernel(const WgradP
 // 3x3 stride-1 weight gradients at image widths that are multiples of 8 go through the all-taps kernel (56x56 x 64 channels at
 // 1280 frames: 0.834 -> 0.470 ms; ResNet-50 step -1.1 %, ResNet-34 -4.2 %). R3M_WG16_HALO=0: per-tap kernel
 static int wg16_halo() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("R3M_WG16_HALO"); v = e ? atoi(e) : 1; }
+  const int v = R3M_ENV_INT("R3M_WG16_HALO", 1);
   return v;
 }
 
@@ -942,7 +924,7 @@ static inline int wgrad_halo_lds_bytes(int W) { return 2 * (64 * 128 + ceil_div(
 static bool wgrad_halo_eligible(const WgradParams& p) {
   // widths that are multiples of 8 (56 x 56: the 64-channel layers, where the per-tap kernel is furthest from its roof)
   return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Ho == p.Hi && p.Wo == p.Wi && (p.Wi & 7) == 0 && p.Wi >= 8 &&
-         p.Hi >= 2 && p.Wi <= 1024 && wgrad_halo_lds_bytes(p.Wi) <= 80 * 1024;
+         p.Hi >= 4 && p.Wi <= 1024 && wgrad_halo_lds_bytes(p.Wi) <= 80 * 1024;
 }
 
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
@@ -951,8 +933,7 @@ static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128
 int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   const bool wide = wg_wide(Co, Ci);
   const int tiles = wide ? (Co / 128) * (Ci / 128) * T : ceil_div(Co, 64) * ceil_div(Ci, 64) * T;
-  static int tgt = -1;     // R3M_WG16_BLOCKS: target block count of the 128x128 launches (experiments)
-  if (tgt < 0) { const char* e = getenv("R3M_WG16_BLOCKS"); tgt = e ? atoi(e) : 0; }
+  const int tgt = R3M_ENV_INT("R3M_WG16_BLOCKS", 0);
   // the all-taps kernel runs one block per (tile, split) for all nine taps: 512 splits of the 64-channel layers fill the chip
   const int narrow_target = (T == 9 && wg16_halo()) ? 512 * 9 : 2560;
   int split = (wide ? (tgt > 0 ? tgt : 1024) : narrow_target) / (tiles > 0 ? tiles : 1);
@@ -974,25 +955,17 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   prof_begin(wide ? KC_WGRAD_WIDE : KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
   p.gx = tilesM * p.tilesN * T;
   {
-    static int il = -1;
-    if (il < 0) { const char* e = getenv("R3M_WG_INTERLEAVE"); il = e ? atoi(e) : 0; }
+    const int il = R3M_ENV_INT("R3M_WG_INTERLEAVE", 0);
     p.interleave = il;
-    static int xc = -1;
-    if (xc < 0) { const char* e = getenv("R3M_WG_XCD"); xc = e ? atoi(e) : 1; }
+    const int xc = R3M_ENV_INT("R3M_WG_XCD", 1);
     p.xcd = xc;
   }
   if (wg16_halo() && wgrad_halo_eligible(p)) {
     p.tilesN = p.Ci / 64;
     p.gx = (p.Co / 64) * p.tilesN;
     const int lds = wgrad_halo_lds_bytes(p.Wi);
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_halo_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-        set_last_error("wgrad3x3_halo(bf16): cannot reserve %d bytes of LDS", lds);
-        return 1;
-      }
-      attr_lds = lds;
-    }
+    static DynLdsOptIn optin;
+    if (int e = ensure_dyn_lds(optin, reinterpret_cast<const void*>(wgrad3x3_halo_bf16_kernel), lds, "wgrad3x3_halo(bf16)")) return e;
     hipLaunchKernelGGL(wgrad3x3_halo_bf16_kernel, dim3(p.gx * splitK), dim3(256), lds, s, p, ceil_div(64 + 2 * p.Wi + 2, 8));
     prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
     prof_end(s);
@@ -1001,8 +974,7 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   const dim3 grid(p.gx * splitK);
   // K steps of 32 rows for the 128x128 tile (32 KB of stages instead of 64: -16 % measured over ResNet-50), 64 rows for the
   // 64x64 tile (32 rows measured +5 % there). R3M_WG16_BK=64 / =32 forces one step size on both (experiments).
-  static int bk = -1;
-  if (bk < 0) { const char* e = getenv("R3M_WG16_BK"); bk = e ? atoi(e) : 0; }
+  const int bk = R3M_ENV_INT("R3M_WG16_BK", 0);
   const bool bk32 = bk == 32 || (bk != 64 && wide);
   if (wide && bk32) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32>), grid, dim3(256), 0, s, p);
   else if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);

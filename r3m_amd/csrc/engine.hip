@@ -473,8 +473,7 @@ static int side_init(Plan& P) {
     // Opt-in. Measured on ResNet-50 F=1280 (profiles/r01 notes in DESIGN.md): co-running wgrad with the BatchNorm-backward
     // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
     // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
-    const char* e = getenv("R3M_SIDE_STREAM");
-    P.use_side = (e && *e && *e != '0') ? 1 : 0;
+    P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0) != 0;
   }
   if (!P.use_side || P.side) return 0;
   if (hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking) != hipSuccess) { set_last_error("side stream: create failed"); return 1; }

@@ -147,9 +147,10 @@ struct LangDims {
   long long X, Hh[4], dA, dB, Wt, wgp, total;
 };
 
-static LangDims lang_dims(int B, int D, int H, int LD) {
+// R = rows of the MLP input: 15 B for the batched step (B clips), or the row count of ONE get_reward call (B = 0)
+static LangDims lang_dims_rows(int R, int B, int D, int H, int LD) {
   LangDims d;
-  d.B = B; d.D = D; d.H = H; d.LD = LD; d.K1 = 2 * D + LD; d.R = 15 * B;
+  d.B = B; d.D = D; d.H = H; d.LD = LD; d.K1 = 2 * D + LD; d.R = R;
   long long o = 0;
   for (int l = 0; l < 5; ++l) {
     const long long in = l == 0 ? d.K1 : H, out = l == 4 ? 1 : H;
@@ -172,7 +173,10 @@ static LangDims lang_dims(int B, int D, int H, int LD) {
   return d;
 }
 
+static LangDims lang_dims(int B, int D, int H, int LD) { return lang_dims_rows(15 * B, B, D, H, LD); }
+
 long long langrew_num_params(int D, int H, int LD) { return lang_dims(1, D, H, LD).n_params; }
+size_t langrew_call_ws_floats(int R, int D, int H, int LD) { return (size_t)lang_dims_rows(R, 0, D, H, LD).total; }
 size_t langrew_ws_floats(int B, int D, int H, int LD) { return (size_t)lang_dims(B, D, H, LD).total; }
 
 static int check_dims(const LangDims& d) {
@@ -181,12 +185,9 @@ static int check_dims(const LangDims& d) {
   return 0;
 }
 
-int langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, float* ws, int B,
-                    int D, int H, int LD, hipStream_t s) {
-  const LangDims d = lang_dims(B, D, H, LD);
-  if (int e = check_dims(d)) return e;
-  hipLaunchKernelGGL(lang_gather_kernel, dim3(d.R), dim3(256), 0, s, alle, feats, perm, ws + d.X, B, D, LD);
-  if (int e = check_launch("lang_gather")) return e;
+// the MLP proper on the rows staged at ws + d.X: 4 x (Linear + ReLU) on the gather-GEMM, Linear(H -> 1) as a GEMV
+static int mlp_forward(const LangDims& d, const float* params, float* scores, float* ws, hipStream_t s) {
+  const int H = d.H;
   const float* in = ws + d.X;
   int K = d.K1;
   for (int l = 0; l < 4; ++l) {
@@ -200,16 +201,24 @@ int langrew_forward(const float* alle, const float* feats, const int* perm, cons
   return check_launch("gemv_fwd");
 }
 
+int langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, float* ws, int B,
+                    int D, int H, int LD, hipStream_t s) {
+  const LangDims d = lang_dims(B, D, H, LD);
+  if (int e = check_dims(d)) return e;
+  hipLaunchKernelGGL(lang_gather_kernel, dim3(d.R), dim3(256), 0, s, alle, feats, perm, ws + d.X, B, D, LD);
+  if (int e = check_launch("lang_gather")) return e;
+  return mlp_forward(d, params, scores, ws, s);
+}
+
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
                       int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s);
 
-// dscore [15B] -> parameter gradients (flat, same layout as params) and dalle += d/d alle. Needs the workspace left by
-// langrew_forward (X and the four hidden activations).
-int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
-                     int H, int LD, int accumulate, hipStream_t s) {
-  const LangDims d = lang_dims(B, D, H, LD);
-  if (int e = check_dims(d)) return e;
+// Needs the workspace left by the forward (X and the four hidden activations).
+// dscore [R] -> parameter gradients (= or +=); returns the buffer holding dX [R, K1] (inside ws) through *dx_out
+static int mlp_backward(const LangDims& d, const float* dscore, const float* params, float* grads, float* ws, int accumulate,
+                        float** dx_out, hipStream_t s) {
+  const int H = d.H;
   float* dA = ws + d.dA;
   float* dB = ws + d.dB;
   float* Wt = ws + d.Wt;
@@ -237,10 +246,67 @@ int langrew_backward(const float* dscore, const int* iperm, const float* params,
       return e;
     float* t = dz; dz = nxt; nxt = t;
   }
-  // dz now holds dX [15B, K1]
+  *dx_out = dz;   // dX [R, K1]
+  return 0;
+}
+
+int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
+                     int H, int LD, int accumulate, hipStream_t s) {
+  const LangDims d = lang_dims(B, D, H, LD);
+  if (int e = check_dims(d)) return e;
+  float* dz = nullptr;
+  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, s)) return e;
   if (dalle) {
     hipLaunchKernelGGL(lang_scatter_kernel, dim3(B, 5), dim3(256), 0, s, dz, iperm, dalle, B, D, LD);
     if (int e = check_launch("lang_scatter")) return e;
+  }
+  return 0;
+}
+
+// ---- ONE evaluation G(e0, eg, le), differentiable: the reference's own calling form (R3M.get_reward, models_r3m.py:78-81 ->
+// LanguageReward.forward, models_language.py:53-55), 15 of them per step in trainer.py:72-92. Same MLP core as the batched
+// pass; the input rows are the concatenation [e0 | eg | le] staged by one copy kernel, the input gradient is split back.
+__global__ __launch_bounds__(256) void lang_concat_kernel(const float* __restrict__ e0, const float* __restrict__ eg,
+                                                           const float* __restrict__ le, float* __restrict__ X, int D, int LD) {
+  const long long row = blockIdx.x;
+  float* x = X + row * (2LL * D + LD);
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    *reinterpret_cast<f32x4*>(x + d) = ld4g(e0 + row * D + d);
+    *reinterpret_cast<f32x4*>(x + D + d) = ld4g(eg + row * D + d);
+  }
+  for (int d = threadIdx.x * 4; d < LD; d += 1024) *reinterpret_cast<f32x4*>(x + 2 * D + d) = ld4g(le + row * LD + d);
+}
+
+__global__ __launch_bounds__(256) void lang_split_kernel(const float* __restrict__ dX, float* __restrict__ de0, float* __restrict__ deg,
+                                                          float* __restrict__ dle, int D, int LD) {
+  const long long row = blockIdx.x;
+  const float* x = dX + row * (2LL * D + LD);
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    if (de0) *reinterpret_cast<f32x4*>(de0 + row * D + d) = ld4g(x + d);
+    if (deg) *reinterpret_cast<f32x4*>(deg + row * D + d) = ld4g(x + D + d);
+  }
+  if (dle)
+    for (int d = threadIdx.x * 4; d < LD; d += 1024) *reinterpret_cast<f32x4*>(dle + row * LD + d) = ld4g(x + 2 * D + d);
+}
+
+int langrew_call_forward(const float* e0, const float* eg, const float* le, const float* params, float* score, float* ws, int R,
+                         int D, int H, int LD, hipStream_t s) {
+  const LangDims d = lang_dims_rows(R, 0, D, H, LD);
+  if (int e = check_dims(d)) return e;
+  hipLaunchKernelGGL(lang_concat_kernel, dim3(R), dim3(256), 0, s, e0, eg, le, ws + d.X, D, LD);
+  if (int e = check_launch("lang_concat")) return e;
+  return mlp_forward(d, params, score, ws, s);
+}
+
+int langrew_call_backward(const float* dscore, const float* params, float* grads, float* de0, float* deg, float* dle, float* ws,
+                          int R, int D, int H, int LD, int accumulate, hipStream_t s) {
+  const LangDims d = lang_dims_rows(R, 0, D, H, LD);
+  if (int e = check_dims(d)) return e;
+  float* dz = nullptr;
+  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, s)) return e;
+  if (de0 || deg || dle) {
+    hipLaunchKernelGGL(lang_split_kernel, dim3(R), dim3(256), 0, s, dz, de0, deg, dle, D, LD);
+    if (int e = check_launch("lang_split")) return e;
   }
   return 0;
 }

@@ -147,15 +147,9 @@ int launch_stem_fwd16(const void* xn16, const float* w147, void* y, float* stats
   prof_bytes((double)stem_xn16_bytes(F) + (double)p.M * 64 * 2);
   const int ntiles = F * 49;
   const int grid = ntiles < 512 ? ntiles : 512;   // persistent blocks (2 per CU): the weight image is converted once per block
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd16_kernel<EPI_STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS) != hipSuccess) {
-      set_last_error("stem_fwd16: cannot reserve %d bytes of LDS", SF_LDS);
-      return 1;
-    }
-    attr_set = true;
-  }
+  static DynLdsOptIn optin_stats, optin_plain;
+  if (int e = ensure_dyn_lds(optin_stats, reinterpret_cast<const void*>(stem_fwd16_kernel<EPI_STATS>), SF_LDS, "stem_fwd16")) return e;
+  if (int e = ensure_dyn_lds(optin_plain, reinterpret_cast<const void*>(stem_fwd16_kernel<0>), SF_LDS, "stem_fwd16")) return e;
   const bf16_t* xn = static_cast<const bf16_t*>(xn16);
   if (stats) hipLaunchKernelGGL((stem_fwd16_kernel<EPI_STATS>), dim3(grid), dim3(256), SF_LDS, s, xn, w147, p, ntiles);
   else hipLaunchKernelGGL((stem_fwd16_kernel<0>), dim3(grid), dim3(256), SF_LDS, s, xn, w147, p, ntiles);

@@ -248,6 +248,19 @@ class HipResNet(nn.Module):
         except Exception:
             pass
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: native plan handles, the activation arena, the flat gradient buffer and the data-parallel
+        hook belong to THIS object (a copied integer handle would be destroyed twice); the copy re-creates them lazily. The
+        reference R3M deep-copies cleanly (plain nn.Module), so must this."""
+        st = self.__dict__.copy()
+        st.update(_plans={}, _arena=None, _flat_g=None, _stage_hook=None, _grad_fresh=True, _live_F=None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        for p in self.parameters():      # gradients were views of the dropped flat buffer
+            p.grad = None
+
     def _run_forward(self, x, training):
         L = _lib.lib()
         F = x.shape[0]
@@ -257,8 +270,9 @@ class HipResNet(nn.Module):
             self._arena = None  # release first: the arena is the dominant HBM allocation
             self._arena = torch.empty(need, dtype=torch.uint8, device=x.device)
         out = torch.empty((F, self.outdim), dtype=torch.float32, device=x.device)
-        _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
-                                        out.data_ptr(), 1 if training else 0, _lib.stream_ptr()), "resnet_forward")
+        with _lib.on(x):
+            _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
+                                            out.data_ptr(), 1 if training else 0, _lib.stream_ptr(x.device)), "resnet_forward")
         if training:
             self._flat_nbt += 1
         self._generation += 1
@@ -273,12 +287,13 @@ class HipResNet(nn.Module):
         h = self._plan(self._live_F)
         g = self.flat_grads()
         accumulate = 0 if self._grad_fresh else 1
-        for stage in range(4):
-            _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), self._arena.data_ptr(), stage,
-                                             stage + 1, accumulate, _lib.stream_ptr()), "resnet_backward")
-            if self._stage_hook is not None:
-                off, cnt = self.stage_range(stage)
-                self._stage_hook(stage, off, cnt)
+        with _lib.on(dh):
+            for stage in range(4):
+                _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), self._arena.data_ptr(), stage,
+                                                 stage + 1, accumulate, _lib.stream_ptr(dh.device)), "resnet_backward")
+                if self._stage_hook is not None:
+                    off, cnt = self.stage_range(stage)
+                    self._stage_hook(stage, off, cnt)
         self._grad_fresh = False
 
     def forward(self, x):

@@ -77,9 +77,10 @@ class _BatchedRewardFn(torch.autograd.Function):
         ws_bytes = L.r3m_langrew_workspace_bytes(B, D, module.hidden_dim, module.lang_dim)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=alle.device)
         scores = torch.empty((15, B), dtype=torch.float32, device=alle.device)
-        _lib.check(L.r3m_langrew_forward(alle.data_ptr(), feats.data_ptr(), perm.data_ptr(), module.flat_params().data_ptr(),
-                                         scores.data_ptr(), ws.data_ptr(), ws_bytes, B, D, module.hidden_dim, module.lang_dim,
-                                         _lib.stream_ptr()), "langrew_forward")
+        with _lib.on(alle):
+            _lib.check(L.r3m_langrew_forward(alle.data_ptr(), feats.data_ptr(), perm.data_ptr(), module.flat_params().data_ptr(),
+                                             scores.data_ptr(), ws.data_ptr(), ws_bytes, B, D, module.hidden_dim, module.lang_dim,
+                                             _lib.stream_ptr(alle.device)), "langrew_forward")
         ctx.module, ctx.ws, ctx.ws_bytes, ctx.dims = module, ws, ws_bytes, (B, D)
         ctx.save_for_backward(perm)
         return scores
@@ -94,13 +95,61 @@ class _BatchedRewardFn(torch.autograd.Function):
         dalle = torch.zeros((B, 5, D), dtype=torch.float32, device=dscores.device)
         g = module.flat_grads()
         accumulate = 0 if module._grad_fresh else 1
-        _lib.check(L.r3m_langrew_backward(dscores.contiguous().data_ptr(), iperm.data_ptr(), module.flat_params().data_ptr(),
-                                          g.data_ptr(), dalle.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes, B, D, module.hidden_dim,
-                                          module.lang_dim, accumulate, _lib.stream_ptr()), "langrew_backward")
+        dscores = dscores.contiguous()
+        with _lib.on(dscores):
+            _lib.check(L.r3m_langrew_backward(dscores.data_ptr(), iperm.data_ptr(), module.flat_params().data_ptr(),
+                                              g.data_ptr(), dalle.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes, B, D, module.hidden_dim,
+                                              module.lang_dim, accumulate, _lib.stream_ptr(dscores.device)), "langrew_backward")
         module._grad_fresh = False
         module._has_grads = True
         ctx.ws = None
         return dalle, None, None, None, None
+
+
+class _RewardCallFn(torch.autograd.Function):
+    """score = G(e0, eg, le) for ONE call, differentiable in e0, eg, le and the head's parameters — what the reference's
+    trainer does 15 times per step through autograd (trainer.py:72-92). All arithmetic in csrc/lang.hip (r3m_langrew_call_*):
+    concat -> 4 x (Linear + ReLU) on the MFMA gather-GEMM -> Linear(H -> 1) GEMV; backward = the batched pass's kernels on
+    this call's rows. Parameter gradients accumulate into the module's flat gradient buffer across the calls of a step."""
+
+    @staticmethod
+    def forward(ctx, e0, eg, le, anchor, module):
+        L = _lib.lib()
+        R, D = e0.shape
+        ws_bytes = L.r3m_langrew_call_workspace_bytes(R, D, module.hidden_dim, module.lang_dim)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=e0.device)
+        score = torch.empty((R,), dtype=torch.float32, device=e0.device)
+        with _lib.on(e0):
+            _lib.check(L.r3m_langrew_call_forward(e0.data_ptr(), eg.data_ptr(), le.data_ptr(), module.flat_params().data_ptr(),
+                                                  score.data_ptr(), ws.data_ptr(), ws_bytes, R, D, module.hidden_dim,
+                                                  module.lang_dim, _lib.stream_ptr(e0.device)), "langrew_call_forward")
+        ctx.module, ctx.ws, ctx.ws_bytes, ctx.dims = module, ws, ws_bytes, (R, D)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        L = _lib.lib()
+        module = ctx.module
+        R, D = ctx.dims
+        if ctx.ws is None:
+            raise RuntimeError("r3m_amd.LanguageReward: backward through the same get_reward call twice (activations were released)")
+        dscore = dscore.to(torch.float32).contiguous()
+        need = ctx.needs_input_grad
+        dev = dscore.device
+        de0 = torch.empty((R, D), dtype=torch.float32, device=dev) if need[0] else None
+        deg = torch.empty((R, D), dtype=torch.float32, device=dev) if need[1] else None
+        dle = torch.empty((R, module.lang_dim), dtype=torch.float32, device=dev) if need[2] else None
+        g = module.flat_grads()
+        accumulate = 0 if module._grad_fresh else 1
+        with _lib.on(dscore):
+            _lib.check(L.r3m_langrew_call_backward(dscore.data_ptr(), module.flat_params().data_ptr(), g.data_ptr(), _lib.ptr(de0),
+                                                   _lib.ptr(deg), _lib.ptr(dle), ctx.ws.data_ptr(), ctx.ws_bytes, R, D,
+                                                   module.hidden_dim, module.lang_dim, accumulate, _lib.stream_ptr(dev)),
+                       "langrew_call_backward")
+        module._grad_fresh = False
+        module._has_grads = True
+        ctx.ws = None
+        return de0, deg, dle, None, None
 
 
 class LanguageReward(nn.Module):
@@ -199,21 +248,20 @@ class LanguageReward(nn.Module):
         return _BatchedRewardFn.apply(alle, feats, lang_perm, anchor, self)
 
     def forward(self, e0, eg, le):
-        """Single evaluation G(e0, eg, le) -> (score[B], {}), reference signature (models_language.py:53-55). Inference helper:
-        runs the HIP Linear chain without autograd; training goes through batched_scores()."""
+        """Single evaluation G(e0, eg, le) -> (score[B], {}), reference signature and semantics (models_language.py:53-55):
+        differentiable in the embeddings and in the head's parameters, so the reference's own 15-call loop
+        (trainer.py:72-92) trains the head and sends the language gradient into the encoder exactly as it does there.
+        Trainer.update of this package uses batched_scores() instead (one pass for the 15 calls)."""
         if not e0.is_cuda:
             raise RuntimeError("r3m_amd.LanguageReward runs on the HIP path only (no CPU fallback)")
-        L = _lib.lib()
-        with torch.no_grad():
-            x = torch.cat([e0, eg, le.to(e0.dtype)], -1).contiguous()
-            M = x.shape[0]
-            P = dict(self.named_parameters())
-            st = _lib.stream_ptr()
-            for li in (0, 2, 4, 6):
-                w, b = P[f"pred.{li}.weight"], P[f"pred.{li}.bias"]
-                y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=x.device)
-                _lib.check(L.r3m_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, w.shape[1], w.shape[0], 1, st),
-                           "linear_fwd")
-                x = y
-            score = x @ P["pred.8.weight"].t() + P["pred.8.bias"]
-        return score.squeeze(), {}
+        lead = e0.shape[:-1]
+        D = e0.shape[-1]
+        if D != self.im_dim or eg.shape != e0.shape or le.shape[:-1] != lead or le.shape[-1] != self.lang_dim:
+            raise ValueError(f"LanguageReward: e0 {tuple(e0.shape)}, eg {tuple(eg.shape)}, le {tuple(le.shape)} "
+                             f"(expected [...,{self.im_dim}] x2 and [...,{self.lang_dim}])")
+        e0 = e0.reshape(-1, D).to(torch.float32).contiguous()
+        eg = eg.reshape(-1, D).to(torch.float32).contiguous()
+        le = le.to(e0.device).reshape(-1, self.lang_dim).to(torch.float32).contiguous()
+        anchor = self.pred._modules["0"].weight
+        score = _RewardCallFn.apply(e0, eg, le, anchor, self)
+        return score.reshape(*lead, 1).squeeze(), {}      # `.squeeze()` as the reference: B = 1 collapses to 0-d

@@ -43,19 +43,20 @@ class _R3MLossFn(torch.autograd.Function):
             perm = torch.arange(B, dtype=torch.int32, device=dev).repeat(6, 1)
         perm = perm.to(device=dev, dtype=torch.int32).contiguous()
         iperm = inverse_permutations(perm).contiguous()
-        st = _lib.stream_ptr()
-        _lib.check(L.r3m_loss_tcn_lp(alle.data_ptr(), perm.data_ptr(), iperm.data_ptr(), dalle.data_ptr(), ws.data_ptr(), ws_bytes,
-                                     B, D, 1 if l2dist else 0, float(l2w), float(l1w), float(tcnw), st), "loss_tcn_lp")
+        st = _lib.stream_ptr(dev)
         dscore = None
         have_lang = scores is not None and langw > 0
-        if have_lang:
-            scores = scores.contiguous()
-            mask = mask.to(device=dev, dtype=torch.float32).contiguous()
-            dscore = torch.empty_like(scores)
-            _lib.check(L.r3m_loss_lang_infonce(scores.data_ptr(), mask.data_ptr(), dscore.data_ptr(), ws.data_ptr(), ws_bytes, B,
-                                               float(langw), st), "loss_lang_infonce")
-        _lib.check(L.r3m_loss_finalize(ws.data_ptr(), ws_bytes, B, 1 if have_lang else 0, metrics.data_ptr(), float(l2w), float(l1w),
-                                       float(tcnw), float(langw) if have_lang else 0.0, st), "loss_finalize")
+        with _lib.on(alle):
+            _lib.check(L.r3m_loss_tcn_lp(alle.data_ptr(), perm.data_ptr(), iperm.data_ptr(), dalle.data_ptr(), ws.data_ptr(), ws_bytes,
+                                         B, D, 1 if l2dist else 0, float(l2w), float(l1w), float(tcnw), st), "loss_tcn_lp")
+            if have_lang:
+                scores = scores.contiguous()
+                mask = mask.to(device=dev, dtype=torch.float32).contiguous()
+                dscore = torch.empty_like(scores)
+                _lib.check(L.r3m_loss_lang_infonce(scores.data_ptr(), mask.data_ptr(), dscore.data_ptr(), ws.data_ptr(), ws_bytes, B,
+                                                   float(langw), st), "loss_lang_infonce")
+            _lib.check(L.r3m_loss_finalize(ws.data_ptr(), ws_bytes, B, 1 if have_lang else 0, metrics.data_ptr(), float(l2w),
+                                           float(l1w), float(tcnw), float(langw) if have_lang else 0.0, st), "loss_finalize")
         ctx.save_for_backward(dalle, dscore)
         ctx.mark_non_differentiable(metrics)
         return metrics[9].clone(), metrics

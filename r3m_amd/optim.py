@@ -15,10 +15,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.owners = list(owners)
         params = [p for o in self.owners for p in o.parameters()]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._step = 0
-        self._m = [None] * len(self.owners)
+        self._steps = [0] * len(self.owners)   # torch.optim.Adam keeps `step` per parameter: an owner that receives its first
+        self._m = [None] * len(self.owners)    # gradient later (the language head) starts its bias correction then
         self._v = [None] * len(self.owners)
         self.grad_scale = 1.0
+
+    def __getstate__(self):
+        # Optimizer.__getstate__ keeps defaults/state/param_groups only; deepcopy(R3M) and pickling must keep the owners
+        # protocol and the moments too (the reference's torch.optim.Adam deep-copies with its state).
+        st = super().__getstate__()
+        st.update(owners=self.owners, _steps=self._steps, _m=self._m, _v=self._v, grad_scale=self.grad_scale)
+        return st
 
     def zero_grad(self, set_to_none=True):
         # Gradients live in persistent flat buffers; "zeroing" = the next backward overwrites them (no memset pass).
@@ -31,7 +38,6 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdam.step(closure) is not supported")
         g0 = self.param_groups[0]
         lr, (b1, b2), eps = g0["lr"], g0["betas"], g0["eps"]
-        self._step += 1
         L = _lib.lib()
         for i, o in enumerate(self.owners):
             p = o.flat_params()
@@ -46,18 +52,26 @@ class FusedAdam(torch.optim.Optimizer):
             n = p.numel()
             pad = (-n) % 4
             assert pad == 0, "flat buffers are padded to multiples of 4 floats"
-            _lib.check(L.r3m_adam_step(p.data_ptr(), g.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr(), n, float(lr),
-                                       float(b1), float(b2), float(eps), self._step, float(self.grad_scale), _lib.stream_ptr()),
-                       "adam_step")
+            self._steps[i] += 1
+            with _lib.on(p):
+                _lib.check(L.r3m_adam_step(p.data_ptr(), g.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr(), n, float(lr),
+                                           float(b1), float(b2), float(eps), self._steps[i], float(self.grad_scale),
+                                           _lib.stream_ptr(p.device)), "adam_step")
+
+    @property
+    def _step(self):
+        """Step count of the first owner (the encoder): what the snapshot's `step` key has always meant."""
+        return self._steps[0]
 
     # state: enough to resume (the reference never saved optimizer state, train_representation.py:123-130)
     def state_dict(self):
-        return {"step": self._step, "exp_avg": [None if m is None else m.cpu() for m in self._m],
+        return {"step": self._steps[0], "steps": list(self._steps), "exp_avg": [None if m is None else m.cpu() for m in self._m],
                 "exp_avg_sq": [None if v is None else v.cpu() for v in self._v], "param_groups": [
                     {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["step"])
+        steps = sd.get("steps")           # round-1 snapshots carry one shared `step`
+        self._steps = [int(s) for s in steps] if steps is not None else [int(sd["step"])] * len(self.owners)
         for i, o in enumerate(self.owners):
             if sd["exp_avg"][i] is not None:
                 dev = o.flat_params().device
@@ -77,7 +91,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.owners = list(owners)
         params = [p for o in self.owners for p in o.parameters()]
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
-        self._step = 0
+        self._steps = [0] * len(self.owners)
         self._buf = [None] * len(self.owners)
         self.grad_scale = 1.0
 
@@ -90,7 +104,6 @@ class FusedSGD(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("FusedSGD.step(closure) is not supported")
         g0 = self.param_groups[0]
-        self._step += 1
         L = _lib.lib()
         for i, o in enumerate(self.owners):
             p = o.flat_params()
@@ -102,6 +115,13 @@ class FusedSGD(torch.optim.Optimizer):
             if g0["momentum"] != 0 and (self._buf[i] is None or self._buf[i].device != p.device or self._buf[i].numel() != p.numel()):
                 self._buf[i] = torch.zeros_like(p)
             buf_ptr = None if self._buf[i] is None else self._buf[i].data_ptr()
-            _lib.check(L.r3m_sgd_step(p.data_ptr(), g.data_ptr(), buf_ptr, p.numel(), float(g0["lr"]), float(g0["momentum"]),
-                                      float(g0["dampening"]), float(g0["weight_decay"]), int(bool(g0["nesterov"])), self._step,
-                                      float(self.grad_scale), _lib.stream_ptr()), "sgd_step")
+            self._steps[i] += 1
+            with _lib.on(p):
+                _lib.check(L.r3m_sgd_step(p.data_ptr(), g.data_ptr(), buf_ptr, p.numel(), float(g0["lr"]), float(g0["momentum"]),
+                                          float(g0["dampening"]), float(g0["weight_decay"]), int(bool(g0["nesterov"])),
+                                          self._steps[i], float(self.grad_scale), _lib.stream_ptr(p.device)), "sgd_step")
+
+    def __getstate__(self):
+        st = super().__getstate__()
+        st.update(owners=self.owners, _steps=self._steps, _buf=self._buf, grad_scale=self.grad_scale)
+        return st

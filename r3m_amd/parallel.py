@@ -23,16 +23,22 @@ import torch.nn as nn
 class GradSync:
     """Mean-all-reduce of slices of flat gradient buffers; device-agnostic (RCCL on GPUs, gloo on CPU in tests)."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force=False):
+        """force=True issues the collectives even on a one-rank group (mean over one rank = identity): the way the RCCL
+        enqueue / stream-ordering path is exercised on a single-GPU box (tests/test_gpu_ddp.py, `torchrun --nproc-per-node 1
+        bench.py`)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)
         self._pending = []   # (work, slice, needs_div)
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"   # RCCL reduces with AVG natively; gloo has SUM only
+        self.launched = 0               # collectives enqueued so far (tests / bench report it)
 
     def reduce_slice(self, flat, offset, count):
-        if self.world == 1 or count == 0:
+        if not self.active or count == 0:
             return
+        self.launched += 1
         sl = flat[offset:offset + count]
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
@@ -46,7 +52,7 @@ class GradSync:
         self._pending.clear()
 
     def broadcast(self, tensor, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(tensor, src=src, group=self.group)
 
 
@@ -67,10 +73,11 @@ class SingleDevice(nn.Module):
 class DistributedR3M(nn.Module):
     """One replica per rank. Construct AFTER torch.distributed.init_process_group and after moving `module` to its GPU."""
 
-    def __init__(self, module, process_group=None):
+    def __init__(self, module, process_group=None, force=False):
         super().__init__()
         self.module = module
-        self.sync = GradSync(process_group)
+        self.sync = GradSync(process_group, force=force)
+        self._head_done = False
         # identical replicas: rank 0's parameters and BatchNorm buffers win
         for owner in self._owners():
             self.sync.broadcast(owner.flat_params())
@@ -81,27 +88,39 @@ class DistributedR3M(nn.Module):
     def _owners(self):
         return list(self.module.encoder_opt.owners)
 
-    def _on_stage(self, stage, offset, count):
-        self.sync.reduce_slice(self.module.convnet.flat_grads(), offset, count)
-
-    def forward(self, *a, **k):
-        return self.module(*a, **k)
-
-    def finish_gradient_sync(self):
-        """Call after backward, before the optimizer step: reduces the (small) language-head gradients and waits for the
-        encoder slices launched during backward."""
+    def _reduce_heads(self):
+        """Gradients of the owners other than the encoder (the language-reward head: 32.5 MB for ResNet-50). The head's
+        backward is complete before the encoder's starts (the encoder needs d loss / d embeddings, which includes the head's
+        input gradient), so its all-reduce goes out FIRST and rides under the whole encoder backward."""
+        if self._head_done:
+            return
+        self._head_done = True
         for owner in self._owners():
             if owner is self.module.convnet:
                 continue
             if getattr(owner, "has_grads", lambda: True)():
                 g = owner.flat_grads()
                 self.sync.reduce_slice(g, 0, g.numel())
+
+    def _on_stage(self, stage, offset, count):
+        if stage == 0:
+            self._reduce_heads()
+        self.sync.reduce_slice(self.module.convnet.flat_grads(), offset, count)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def finish_gradient_sync(self):
+        """Call after backward, before the optimizer step: waits for the slices launched during backward (and reduces the
+        head gradients now if no encoder backward ran, e.g. a frozen encoder)."""
+        self._reduce_heads()
         self.sync.finish()
+        self._head_done = False
 
 
-def make_network_wrapper(model):
+def make_network_wrapper(model, force=False):
     """What `make_network` (train_representation.py:27-31) returns here: DistributedR3M when a process group exists and
-    world_size > 1, else the trivial wrapper."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return DistributedR3M(model)
+    world_size > 1 (or `force`: one-rank group, collectives still issued), else the trivial wrapper."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        return DistributedR3M(model, force=force)
     return SingleDevice(model)

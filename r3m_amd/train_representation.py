@@ -25,6 +25,15 @@ from .utils.logger import Logger
 from .utils.prefetch import CudaPrefetcher
 
 
+def filter_frozen_text_keys(state_dict):
+    """Reference snapshots written with langweight > 0 carry the frozen DistilBERT as `module.lang_enc.model.*`
+    (it is a registered submodule there, /root/reference/r3m/models/models_language.py:19-20); here LangEncoder owns no
+    parameters (frozen features are an input), so those keys are dropped on load — every other key stays under strict
+    loading. The reverse direction (reference code loading a snapshot written here with langweight > 0) needs
+    strict=False on the reference side for the same keys: INTEGRATION.md §3."""
+    return {k: v for k, v in state_dict.items() if ".lang_enc." not in k and not k.startswith("lang_enc.")}
+
+
 def make_network(cfg_agent):
     model = cfgmod.instantiate(cfg_agent)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -104,7 +113,7 @@ class Workspace:
 
     def load_snapshot(self, snapshot_path):
         payload = torch.load(snapshot_path, map_location="cpu")
-        self.model.load_state_dict(payload['r3m'])
+        self.model.load_state_dict(filter_frozen_text_keys(payload['r3m']))
         if 'global_step' in payload:
             self._global_step = payload['global_step']
         else:

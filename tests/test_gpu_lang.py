@@ -171,3 +171,115 @@ def test_langrew_c_abi_vs_torch(hip, B, D, H, LD):
             assert e < 1e-4, (tuple(t.shape), e)
             off += k
     assert gref.numel() == n
+
+
+def _infonce_torch(scores, mask):
+    """trainer.py:95-110 on a [15,B] score table in the batched row order (pos1-3, in-clip negs 1-3, then k-major permuted negs)."""
+    eps = 1e-8
+    tot = 0
+    for j in range(3):
+        pos = scores[j]
+        negs = torch.stack([scores[3 + j]] + [scores[6 + 3 * k + j] for k in range(3)], -1)
+        tot = tot - torch.log(eps + (torch.exp(pos) / (eps + torch.exp(pos) + torch.exp(negs).sum(-1))))
+    return ((tot / 3) * mask).mean()
+
+
+def test_reference_style_15_call_loop_equals_batched(hip, golden_dir):
+    """VERDICT r1 #1 / SURVEY A5: the reference's trainer calls model.module.get_reward 15 times WITH autograd
+    (/root/reference/r3m/trainer.py:72-92, restated below call for call). Through the differentiable HIP
+    LanguageReward.forward that loop must give the same scores, the same d loss/d embeddings and the same head gradients as
+    the one-pass batched_scores() — and the scores of the reference's own run (golden G3)."""
+    from oracle import detgen
+    from r3m_amd import R3M
+    sys.path.insert(0, golden_dir)
+    from make_golden import make_alle
+    g = np.load(os.path.join(golden_dir, "loss_l2.npz"))
+    B, D = 8, 512
+    m = R3M("cuda", 1e-4, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0)
+    m.lang_rew.load_state_dict(_lang_state(m.lang_rew))
+    m = m.to(DEV)
+    rew = m.lang_rew
+    feats = torch.from_numpy(detgen.uniform("langfeat", (B, 768), -0.6, 0.6)).to(DEV)
+    mask = torch.ones(B, device=DEV)
+    mask[5] = 0.0
+    perms = torch.from_numpy(g["perms"])[0:9]
+
+    # ---- the reference's loop (trainer.py:70-92), 15 autograd calls through R3M.get_reward ----
+    alle = torch.from_numpy(make_alle(B, D, "alle")).to(DEV).requires_grad_(True)
+    e0, eg, es0, es1, es2 = (alle[:, i] for i in range(5))
+    rows = [None] * 15
+    rows[0] = m.get_reward(e0, eg, feats)[0]
+    rows[1] = m.get_reward(e0, es1, feats)[0]
+    rows[2] = m.get_reward(e0, es2, feats)[0]
+    rows[3] = m.get_reward(e0, e0, feats)[0]
+    rows[4] = m.get_reward(e0, es0, feats)[0]
+    rows[5] = m.get_reward(e0, es1, feats)[0]
+    for k in range(3):
+        for j, other in enumerate((eg, es1, es2)):
+            pi = perms[3 * k + j].to(DEV)
+            rows[6 + 3 * k + j] = m.get_reward(e0[pi], other[pi], feats)[0]
+    assert all(r.shape == (B,) and r.requires_grad for r in rows)
+    loop_scores = torch.stack(rows)
+    assert rel_err(loop_scores.detach().cpu().numpy(), g["scores"])[0] < 1e-5        # the reference's own scores
+    m.encoder_opt.zero_grad()
+    _infonce_torch(loop_scores, mask).backward()
+    assert rew.has_grads()
+    dalle_loop = alle.grad.clone()
+    grads_loop = rew.flat_grads().clone()
+
+    # ---- the batched pass under the same loss ----
+    alle2 = torch.from_numpy(make_alle(B, D, "alle")).to(DEV).requires_grad_(True)
+    scores = rew.batched_scores(alle2, feats, perms.to(torch.int32).to(DEV))
+    assert rel_err(loop_scores.detach().cpu().numpy(), scores.detach().cpu().numpy())[0] < 1e-6
+    m.encoder_opt.zero_grad()
+    _infonce_torch(scores, mask).backward()
+    e_max, e_l2 = rel_err(dalle_loop.cpu().numpy(), alle2.grad.cpu().numpy())
+    print(f"15-call loop vs batched: dalle max-rel {e_max:.3e} l2 {e_l2:.3e}")
+    assert e_max < 1e-4
+    gb = rew.flat_grads()
+    for name, off, shape in rew._layout:
+        n = int(np.prod(shape))
+        e = rel_err(grads_loop[off:off + n].cpu().numpy(), gb[off:off + n].cpu().numpy())[0]
+        assert e < 1e-4, (name, e)
+
+    # ---- and the head really trains from the loop: one Adam step moves every tensor of the head ----
+    before = rew.flat_params().clone()
+    m.encoder_opt.step()
+    moved = (rew.flat_params() - before).abs()
+    for name, off, shape in rew._layout:
+        n = int(np.prod(shape))
+        assert float(moved[off:off + n].max()) > 0, name
+
+
+def test_single_call_reward_edge_cases(hip):
+    """LanguageReward.forward: B = 1 collapses to a 0-d score like the reference's .squeeze() (models_language.py:55); no-grad
+    calls work; wrong shapes raise; gradient w.r.t. the text features is available too."""
+    from r3m_amd.models_language import LanguageReward
+    rew = LanguageReward(None, 64, 64, 32)
+    rew.load_state_dict(_lang_state(rew))
+    rew = rew.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    e0, eg, le = torch.rand((1, 64), generator=g).to(DEV), torch.rand((1, 64), generator=g).to(DEV), torch.rand((1, 32), generator=g).to(DEV)
+    s, info = rew(e0, eg, le)
+    assert s.dim() == 0 and info == {}
+    with torch.no_grad():
+        s2, _ = rew(e0, eg, le)
+    assert float(s) == float(s2) and not s2.requires_grad
+    with pytest.raises(ValueError):
+        rew(e0[:, :32], eg, le)
+    # torch-CPU MLP as the checker, all three input gradients
+    import torch.nn as nn
+    P = {k: v.detach().cpu() for k, v in rew.state_dict().items()}
+    x = [t.detach().cpu().repeat(3, 1).clone().requires_grad_(True) for t in (e0, eg, le)]
+    h = torch.cat(x, -1)
+    for li in (0, 2, 4, 6):
+        h = torch.relu(h @ P[f"pred.{li}.weight"].t() + P[f"pred.{li}.bias"])
+    ref = (h @ P["pred.8.weight"].t() + P["pred.8.bias"]).squeeze()
+    ref.sum().backward()
+    xg = [t.detach().repeat(3, 1).clone().requires_grad_(True) for t in (e0, eg, le)]
+    rew.mark_grads_stale()
+    sg, _ = rew(*xg)
+    sg.sum().backward()
+    assert rel_err(sg.detach().cpu().numpy(), ref.detach().numpy())[0] < 1e-5
+    for a, b in zip(xg, x):
+        assert rel_err(a.grad.cpu().numpy(), b.grad.numpy())[0] < 1e-4

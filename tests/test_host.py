@@ -133,3 +133,59 @@ def test_precision_option_is_plumbed():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = config.load_config(os.path.join(root, "r3m_amd", "cfgs", "config_rep.yaml"), ["agent.precision=bf16"])
     assert cfg.agent.precision == "bf16"
+
+
+def test_deepcopy_and_pickle_drop_native_handles():
+    """copy.deepcopy(R3M) must not duplicate native plan handles / the arena, and the optimizer copy must keep the
+    owners protocol, its per-owner step counters and moments (the reference R3M + torch.optim.Adam deep-copy cleanly)."""
+    import pickle
+    from r3m_amd import R3M
+    m = R3M("cpu", 1e-4, 64, size=18, langweight=1.0, tcnweight=1.0)
+    enc = m.convnet
+    enc._plans = {8: 0xdeadbeef}                       # what a GPU forward would have left behind
+    enc._arena = torch.zeros(16, dtype=torch.uint8)
+    enc.flat_grads()
+    enc._stage_hook = lambda *a: None
+    m.encoder_opt._steps = [3, 1]
+    m.encoder_opt._m[0] = torch.full_like(enc.flat_params(), 0.5)
+    m.encoder_opt._v[0] = torch.full_like(enc.flat_params(), 0.25)
+    try:
+        for m2 in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+            e2 = m2.convnet
+            assert e2._plans == {} and e2._arena is None and e2._flat_g is None and e2._stage_hook is None
+            assert all(p.grad is None for p in e2.parameters())
+            e2._ensure()
+            assert e2._is_flat() and e2.flat_params().data_ptr() != enc.flat_params().data_ptr()
+            assert torch.equal(e2.flat_params(), enc.flat_params())
+            o2 = m2.encoder_opt
+            assert o2.owners[0] is e2 and o2.owners[1] is m2.lang_rew          # owners follow the copy, not the original
+            assert o2._steps == [3, 1] and torch.equal(o2._m[0], m.encoder_opt._m[0]) and o2._m[1] is None
+            assert o2._m[0].data_ptr() != m.encoder_opt._m[0].data_ptr()
+            assert {id(p) for g in o2.param_groups for p in g["params"]} == {id(p) for p in m2.parameters()}
+        assert enc._plans == {8: 0xdeadbeef}           # the original keeps its own handles
+    finally:
+        enc._plans = {}                                # fake handle: never hand it to r3m_resnet_destroy
+
+
+def test_adam_step_is_per_owner_and_persisted():
+    """torch.optim.Adam keeps `step` per parameter — an owner without gradients (language head before its first
+    backward) must not advance its bias correction; state_dict carries the per-owner counters and reads round-1 files."""
+    from r3m_amd import R3M
+    m = R3M("cpu", 1e-4, 64, size=18, langweight=1.0, tcnweight=1.0)
+    opt = m.encoder_opt
+    assert opt._steps == [0, 0]
+    sd = opt.state_dict()
+    assert sd["steps"] == [0, 0] and sd["step"] == 0
+    opt.load_state_dict({**sd, "steps": [5, 2]})
+    assert opt._steps == [5, 2] and opt._step == 5
+    legacy = {k: v for k, v in sd.items() if k != "steps"}
+    legacy["step"] = 7
+    opt.load_state_dict(legacy)
+    assert opt._steps == [7, 7]
+
+
+def test_snapshot_filter_drops_only_frozen_text_keys():
+    from r3m_amd.train_representation import filter_frozen_text_keys
+    sd = {"module.convnet.conv1.weight": 1, "module.lang_rew.pred.0.weight": 2, "module.lang_enc.model.embeddings.w": 3,
+          "lang_enc.model.x": 4}
+    assert list(filter_frozen_text_keys(sd)) == ["module.convnet.conv1.weight", "module.lang_rew.pred.0.weight"]

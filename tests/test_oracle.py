@@ -115,3 +115,23 @@ def test_bf16_emulation_checker_is_sane():
     assert not torch.equal(g, g.to(torch.bfloat16).to(g.dtype))          # weight gradients are NOT rounded to bf16
     q = bf16_emul._QAct.apply(torch.tensor([1.0 + 2.0 ** -10], dtype=torch.float64, requires_grad=True))
     assert float(q) == 1.0                                               # 2^-10 is below bf16 resolution at 1.0
+
+
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_kink_table_is_consistent_with_fp64_golden(golden_dir, size):
+    """tests/golden/encoder_r*_kink.npz (make_golden.encoder_kink_golden): near-zero pre-activations of the last block in the
+    float64 oracle and their terms in the last BatchNorm's gradients. Cheap consistency checks here; for ResNet-34 the table
+    must contain the element whose flip is the 1.344e-3 / 1.807e-4 that round 1's parity report showed for the HIP path."""
+    k = np.load(os.path.join(golden_dir, f"encoder_r{size}_kink.npz"))
+    g64 = np.load(os.path.join(golden_dir, f"encoder_r{size}_fp64.npz"))
+    lb = "layer4.2.bn3" if size == 50 else ("layer4.1.bn2" if size == 18 else "layer4.2.bn2")
+    C = g64["grad_" + lb + ".weight"].shape[0]
+    n = len(k["idx"])
+    assert n > 0 and all(len(k[key]) == n for key in ("channel", "z", "dgamma", "dbeta"))
+    assert np.all(np.abs(k["z"]) < float(k["tau"])) and np.all(np.diff(np.abs(k["z"])) >= 0)
+    assert np.all(k["channel"] == (k["idx"] // 49) % C) and np.all((k["dbeta"] > 0.5 / 49) & (k["dbeta"] < 1.5 / 49))
+    if size == 34:
+        ng = np.linalg.norm(g64["grad_" + lb + ".weight"].astype(np.float64))
+        nb = np.linalg.norm(g64["grad_" + lb + ".bias"].astype(np.float64))
+        eff = [(abs(dg) / ng, db / nb) for dg, db in zip(k["dgamma"], k["dbeta"])]
+        assert any(abs(a - 1.344e-3) < 2e-6 and abs(b - 1.807e-4) < 2e-7 for a, b in eff), eff

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Experiment build: every source compiled with -DR3M_PROBES (environment switches + timing probes of DESIGN.md §5b) into
+# r3m_amd/lib/variants/libr3m_hip_probes.so — select it with R3M_HIP_LIB=<that path>. The shipped library (csrc/build.sh) has neither.
+# usage: build_probes.sh [extra hipcc flags]
+set -e
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
+SRC="$ROOT/r3m_amd/csrc"; OBJ="$ROOT/build/obj_probes"; OUT="$ROOT/r3m_amd/lib/variants"; mkdir -p "$OBJ" "$OUT"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DR3M_PROBES $*"
+pids=()
+for f in conv conv_bf16 stem_bf16 bn loss adam lang augment engine capi; do
+  if [ ! -f "$OBJ/$f.o" ] || [ "$SRC/$f.hip" -nt "$OBJ/$f.o" ] || [ "$SRC/common.h" -nt "$OBJ/$f.o" ] || [ "$SRC/conv_dev.h" -nt "$OBJ/$f.o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" & pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libr3m_hip_probes.so" "$OBJ"/*.o
+echo "built $OUT/libr3m_hip_probes.so"
