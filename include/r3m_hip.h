@@ -170,6 +170,12 @@ int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
  * rctraj (one box per clip), 1 for rc. */
 int r3m_crop_resize(const void* frames, int frames_are_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi,
                     int Ho, int Wo, int frames_per_box, r3m_stream_t stream);
+/* R3M.forward's branch for inputs that are not 224 x 224 (r3m/models/models_r3m.py:85-90: transforms.Resize(256) +
+ * CenterCrop(224) on x/255): bilinear resize of the whole frame to resized_h x resized_w (align_corners=False, no antialias) of
+ * which only the Ho x Wo window at (top, left) is computed. frames [N,C,Hi,Wi] uint8 or float 0..255 -> out [N,C,Ho,Wo] float
+ * 0..255. The caller derives resized_h/w and the window with torchvision's rounding (r3m_amd/augment.py). */
+int r3m_resize_crop(const void* frames, int frames_are_u8, float* out, long long N, int C, int Hi, int Wi, int resized_h,
+                    int resized_w, int top, int left, int Ho, int Wo, r3m_stream_t stream);
 
 /* LanguageReward, all 15 evaluations of a step batched (r3m/trainer.py:72-92 calling r3m/models/models_r3m.py:78-81 and
  * r3m/models/models_language.py:43-55). alle [B,5,D]; feats [B,lang_dim] = frozen sentence features (LangEncoder output,

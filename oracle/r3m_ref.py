@@ -116,3 +116,19 @@ def train_step_ref(model, frames, tcn_perm=None, lang_feats=None, lang_mask=None
         full_loss.backward()
         model.encoder_opt.step()
     return metrics
+
+
+def resize_center_crop_ref(obs, size=256, crop=224):
+    """The non-224 branch of R3M.forward (/root/reference/r3m/models/models_r3m.py:85-90): transforms.Resize(256) then
+    CenterCrop(224) applied to obs/255. torchvision (0.8.2, un-vendored) restated for tensors: resize = bilinear
+    F.interpolate (align_corners=False, no antialias) with the smaller edge -> size and the other edge int(size * long / short);
+    centre crop offsets int(round((dim - crop) / 2)). Input 0..255, output 0..255 (scaled back, to compose with R3MRef.forward)."""
+    x = obs.float() / 255.0
+    h, w = x.shape[-2:]
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nh, nw = size, int(size * w / h)
+    x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
+    top, left = int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+    return x[..., top:top + crop, left:left + crop] * 255.0

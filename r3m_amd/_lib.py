@@ -83,6 +83,7 @@ SIGNATURES = {
     "r3m_avgpool_bwd_dt": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_linear_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f]),
     "r3m_crop_resize": (c_i, [c_f, c_i, c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_resize_crop": (c_i, [c_f, c_i, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_num_params": (c_ll, [c_i, c_i, c_i]),
     "r3m_langrew_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "r3m_langrew_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),

@@ -138,6 +138,8 @@ int launch_sgd(float* p, const float* g, float* momentum_buf, long long n, doubl
 // augment.hip
 int launch_crop_resize(const void* in, int in_is_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,
                        int Wo, int frames_per_box, hipStream_t s);
+int launch_resize_crop(const void* in, int in_is_u8, float* out, long long N, int C, int Hi, int Wi, int full_Ho, int full_Wo,
+                       int top, int left, int Ho, int Wo, hipStream_t s);
 // lang.hip
 long long langrew_num_params(int D, int H, int LD);
 size_t langrew_ws_floats(int B, int D, int H, int LD);
@@ -468,6 +470,12 @@ int r3m_crop_resize(const void* frames, int frames_are_u8, const int* boxes, flo
                     int Wo, int frames_per_box, r3m_stream_t stream) {
   R3M_REQUIRE(frames && boxes && out, "crop_resize: null argument");
   return launch_crop_resize(frames, frames_are_u8, boxes, out, N, C, Hi, Wi, Ho, Wo, frames_per_box, S(stream));
+}
+
+int r3m_resize_crop(const void* frames, int frames_are_u8, float* out, long long N, int C, int Hi, int Wi, int resized_h, int resized_w,
+                    int top, int left, int Ho, int Wo, r3m_stream_t stream) {
+  R3M_REQUIRE(frames && out, "resize_crop: null argument");
+  return launch_resize_crop(frames, frames_are_u8, out, N, C, Hi, Wi, resized_h, resized_w, top, left, Ho, Wo, S(stream));
 }
 
 size_t r3m_loss_workspace_bytes(int B) { return loss_workspace_floats(B) * 4; }

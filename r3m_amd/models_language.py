@@ -23,13 +23,63 @@ epsilon = 1e-8
 
 
 class LangEncoder(nn.Module):
-    def __init__(self, device, finetune=False, scratch=False):
+    """Frozen sentence features. `mask_padding=False` (default) is the reference: `last_hidden_state.mean(1)` over ALL token
+    positions, padding included (models_language.py:34), so a sentence's feature depends on the longest sentence of its batch;
+    `mask_padding=True` averages over the real tokens only (batch-independent — what an offline per-sentence cache assumes).
+    Features are computed ONCE per call; Trainer.update calls this once per step where the reference re-runs DistilBERT in each
+    of its 15 get_reward calls on the same sentences (trainer.py:72-92)."""
+
+    def __init__(self, device, finetune=False, scratch=False, mask_padding=False):
         super().__init__()
         self.device = device
         self.modelname = "distilbert-base-uncased"
         self.lang_size = 768
+        self.mask_padding = bool(mask_padding)
         self.feature_cache = {}       # sentence -> [768] tensor (offline-precomputed features)
-        self._hf = None               # (tokenizer, model), loaded lazily from local files only
+        self._hf = None               # (tokenizer, model): use_backend(), or loaded lazily from local files only
+        self.encoder_calls = 0        # transformer passes so far (tests: once per step, none on cache hits)
+
+    def use_backend(self, tokenizer, model):
+        """Plug a tokenizer + transformer (HuggingFace calling convention) instead of loading `distilbert-base-uncased` from
+        the local cache. The model is frozen: eval mode, no gradients — the reference's DistilBERT is never trained either
+        (under no_grad, models_language.py:29), but follows model.train() into dropout; here it does not."""
+        model = model.to(self.device).eval()
+        for p in model.parameters():
+            p.requires_grad_(False)
+        self._hf = (tokenizer, model)
+        return self
+
+    def train(self, mode=True):       # the frozen text model stays in eval mode whatever the step does (trainer.py:31)
+        super().train(mode)
+        if self._hf is not None:
+            self._hf[1].eval()
+        return self
+
+    def encode(self, langs):
+        """[len(langs), 768] features of a list of sentences in ONE transformer pass (models_language.py:29-34)."""
+        tok, model = self._load_hf()
+        with torch.no_grad():
+            enc = tok(list(langs), return_tensors="pt", padding=True)
+            am = enc["attention_mask"].to(self.device)
+            out = model(enc["input_ids"].to(self.device), attention_mask=am).last_hidden_state
+            self.encoder_calls += 1
+            if self.mask_padding:
+                w = am.to(out.dtype).unsqueeze(-1)
+                return (out * w).sum(1) / w.sum(1).clamp_min(1.0)
+            return out.mean(1)         # mean over ALL positions incl. padding, as the reference does
+
+    def precompute(self, sentences, batch_size=256):
+        """Fill feature_cache for a corpus (offline). With the reference's pooling a feature depends on its
+        batch's longest sentence, so a cache is only faithful with mask_padding=True — enforced."""
+        if not self.mask_padding:
+            raise ValueError("LangEncoder.precompute: the reference's mean-over-padding features depend on the batch they were "
+                             "computed in; build the cache with LangEncoder(..., mask_padding=True)")
+        todo = [s for s in dict.fromkeys(sentences) if s not in self.feature_cache]
+        for i in range(0, len(todo), batch_size):
+            chunk = todo[i:i + batch_size]
+            for s, f in zip(chunk, self.encode(chunk)):
+                self.feature_cache[s] = f.detach().clone()
+        return len(todo)
 
     def _load_hf(self):
         if self._hf is None:
@@ -55,11 +105,7 @@ class LangEncoder(nn.Module):
             pass
         if langs and all(s in self.feature_cache for s in langs):
             return torch.stack([self.feature_cache[s] for s in langs]).to(self.device)
-        tok, model = self._load_hf()
-        with torch.no_grad():                          # models_language.py:29-34
-            enc = tok(langs, return_tensors="pt", padding=True)
-            out = model(enc["input_ids"].to(self.device), attention_mask=enc["attention_mask"].to(self.device)).last_hidden_state
-            return out.mean(1)                         # mean over ALL positions incl. padding, as the reference does
+        return self.encode(langs)
 
 
 class _Node(nn.Module):

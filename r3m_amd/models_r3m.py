@@ -73,17 +73,10 @@ class R3M(nn.Module):
 
     def forward(self, obs, num_ims=1, obs_shape=[3, 224, 224]):
         if list(obs_shape) != [3, 224, 224]:
-            # models_r3m.py:85-90: Resize(256) + CenterCrop(224) before Normalize — off the pre-training hot path
-            # (frames arrive as 224x224). Bilinear resample of the raw 0..255 frame; scale and crop commute with /255.
-            obs = obs.float()
-            h, w = obs.shape[-2:]
-            if h <= w:
-                nh, nw = 256, max(1, int(256 * w / h))
-            else:
-                nh, nw = max(1, int(256 * h / w)), 256
-            obs = torch.nn.functional.interpolate(obs, size=(nh, nw), mode="bilinear", align_corners=False)
-            top, left = int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))
-            obs = obs[..., top:top + 224, left:left + 224]
+            # models_r3m.py:85-90: Resize(256) + CenterCrop(224) before Normalize — off the pre-training hot path (frames arrive
+            # as 224x224; example.py users with other sizes land here). One HIP gather pass that computes only the crop window.
+            from .augment import resize_center_crop
+            obs = resize_center_crop(obs.reshape(-1, *obs.shape[-3:]))
         # "Input must be [0, 255], [3,224,224]" (models_r3m.py:96): x.float()/255 -> Normalize -> convnet, all in the engine
         return self.convnet(obs)
 

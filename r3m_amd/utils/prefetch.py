@@ -13,6 +13,7 @@ class CudaPrefetcher:
         self.transform = transform          # optional GPU-side transform (e.g. the rc/rctraj crop), run on the copy stream
         self.stream = torch.cuda.Stream(device=device)
         self._next = None
+        self.copy_events = None             # (start, end) timing events of the most recent host->HBM copy, on the copy stream
         self._preload()
 
     def _preload(self):
@@ -23,11 +24,15 @@ class CudaPrefetcher:
             return
         if not frames.is_pinned():
             frames = frames.pin_memory()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(self.stream):
-            x = frames.to(self.device, non_blocking=True)
+            t0.record(self.stream)
+            x = frames.to(self.device, non_blocking=True)       # uint8 stays uint8 across PCIe (4x fewer bytes than fp32)
+            t1.record(self.stream)
             if self.transform is not None:
                 x = self.transform(x)
             x = x.float()
+        self.copy_events = (t0, t1)
         ev = torch.cuda.Event()
         ev.record(self.stream)
         self._next = (x, labels, ev)

@@ -250,6 +250,72 @@ def step_golden(size=18, B=2, nsteps=2):
     print("step", [out[f"metric_values_{s}"] for s in range(nsteps)])
 
 
+def lang_state(module):
+    sd, full = {}, module.state_dict()
+    for k, v in full.items():
+        fan_in = v.shape[1] if v.dim() == 2 else full[k.replace("bias", "weight")].shape[1]
+        a = 1.0 / np.sqrt(fan_in)
+        sd[k] = torch.from_numpy(detgen.uniform("lr" + k, tuple(v.shape), -a, a))
+    return sd
+
+
+def language_reward_golden(D, B=4):
+    """G4: the reference's LanguageReward (models_language.py:37-55) forward + backward at D = 512 and D = 2048."""
+    _, lang, _ = by_path.load_reference()
+    rew = lang.LanguageReward(None, D, 1024, 768)
+    rew.load_state_dict(lang_state(rew))
+    e0 = torch.from_numpy(np.maximum(detgen.uniform(f"g4e0_{D}", (B, D), -0.3, 1.0), 0)).requires_grad_(True)
+    eg = torch.from_numpy(np.maximum(detgen.uniform(f"g4eg_{D}", (B, D), -0.3, 1.0), 0)).requires_grad_(True)
+    le = torch.from_numpy(detgen.uniform(f"g4le_{D}", (B, 768), -0.6, 0.6))
+    score, info = rew(e0, eg, le)
+    cw = torch.from_numpy(detgen.uniform("g4cw", (B,), 0.5, 1.5))
+    (score * cw).sum().backward()
+    out = {"score": score.detach().numpy(), "de0": e0.grad.numpy(), "deg": eg.grad.numpy(),
+           "grad_pred.8.weight": rew.pred[8].weight.grad.numpy().copy(), "grad_pred.0.bias": rew.pred[0].bias.grad.numpy().copy()}
+    for k, p_ in rew.named_parameters():
+        out["gradnorm_" + k] = np.array(float(p_.grad.double().norm()))
+    np.savez_compressed(os.path.join(OUT, f"langrew_d{D}.npz"), **out)
+    print("langrew", D, out["score"])
+
+
+def adam_golden(nsteps=3):
+    """G6: torch.optim.Adam(lr=1e-4) — the optimizer the reference builds (models_r3m.py:76) — three steps on a small tensor."""
+    n = 4096
+    p = torch.from_numpy(detgen.uniform("g6p", (n,), -1.0, 1.0)).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-4)
+    out = {}
+    for i in range(nsteps):
+        p.grad = torch.from_numpy(detgen.uniform(f"g6g{i}", (n,), -1.0, 1.0) * np.float32(10.0 ** (i - 1)))
+        opt.step()
+        out[f"p_{i}"] = p.detach().numpy().copy()
+    st = opt.state[p]
+    out["exp_avg"], out["exp_avg_sq"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "adam.npz"), **out)
+    print("adam", out["p_2"][:3])
+
+
+def lang_encoder_golden():
+    """G7: the reference's OWN LangEncoder.forward (models_language.py:23-35: tokenise, transformer, mean(1) over all positions)
+    with `AutoTokenizer/AutoModel.from_pretrained` answering with the tiny stand-ins of oracle/tiny_text.py (the pretrained
+    files are absent from the image): the whole batch, and a batch of two equally short sentences (no padding -> different features for
+    the SAME sentences: the padding quirk)."""
+    import transformers
+    from oracle import tiny_text
+    _, lang, _ = by_path.load_reference()
+    saved = transformers.AutoTokenizer.from_pretrained, transformers.AutoModel.from_pretrained
+    transformers.AutoTokenizer.from_pretrained = staticmethod(lambda *a, **k: tiny_text.WhitespaceTokenizer())
+    transformers.AutoModel.from_pretrained = staticmethod(lambda *a, **k: tiny_text.tiny_distilbert())
+    try:
+        enc = lang.LangEncoder("cpu")
+    finally:
+        transformers.AutoTokenizer.from_pretrained, transformers.AutoModel.from_pretrained = saved
+    enc.eval()
+    out = {"feats_all": enc(tiny_text.SENTENCES).numpy(), "feats_short": enc([tiny_text.SENTENCES[0], tiny_text.SENTENCES[3]]).numpy(),
+           "feats_array_input": enc(np.array(tiny_text.SENTENCES[3:6])).numpy()}
+    np.savez_compressed(os.path.join(OUT, "lang_encoder_tiny.npz"), **out)
+    print("lang_encoder", out["feats_all"].shape, float(np.abs(out["feats_all"][0] - out["feats_short"][0]).max()))
+
+
 if __name__ == "__main__":
     assert by_path.available(), "/root/reference is required to (re)generate goldens"
     for size in (18, 34, 50):
@@ -259,3 +325,7 @@ if __name__ == "__main__":
     loss_golden(True)
     loss_golden(False)
     step_golden()
+    language_reward_golden(512)
+    language_reward_golden(2048)
+    adam_golden()
+    lang_encoder_golden()

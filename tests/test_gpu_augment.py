@@ -37,3 +37,48 @@ def test_box_sampler_statistics():
     assert area.min() >= 0.19 and area.max() <= 1.0 and 0.5 < float(area.mean()) < 0.7
     assert ratio.min() > 0.70 and ratio.max() < 1.40
     assert (b[:, 0] + b[:, 2] <= 224).all() and (b[:, 1] + b[:, 3] <= 224).all() and (b[:, :2] >= 0).all()
+
+
+@pytest.mark.parametrize("hw", [(500, 500), (240, 427), (600, 300), (256, 256), (224, 300)])
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_resize_center_crop_branch_matches_oracle(hip, hw, dtype):
+    """R3M.forward for inputs that are not 224x224 (/root/reference/r3m/models/models_r3m.py:85-90: Resize(256) + CenterCrop(224)
+    on x/255; example.py feeds a 500x500 image): the one-pass HIP gather (csrc/augment.hip) against the oracle's restatement of
+    the torchvision transforms (oracle/r3m_ref.resize_center_crop_ref), incl. non-square frames in both orientations."""
+    from oracle import r3m_ref
+    from r3m_amd import augment
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randint(0, 256, (3, 3, H, W), generator=g, dtype=torch.uint8)
+    ref = r3m_ref.resize_center_crop_ref(x)
+    assert ref.shape == (3, 3, 224, 224)
+    out = augment.resize_center_crop(x.to("cuda:0").to(dtype)).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-4)
+
+
+def test_r3m_forward_takes_the_resize_branch(hip):
+    """model(obs, obs_shape=[3,500,500]) == model(Resize+CenterCrop(obs)) — the public forward with the reference's signature."""
+    import numpy as np
+    from oracle import detgen, r3m_ref
+    from r3m_amd import R3M
+    m = R3M("cuda", 1e-4, 1024, size=18, langweight=0.0, tcnweight=1.0)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()})
+    m = m.to("cuda:0").eval()
+    x = torch.from_numpy(detgen.frames("big", (2, 3, 500, 500)))
+    with torch.no_grad():
+        h_branch = m(x.to("cuda:0"), obs_shape=[3, 500, 500]).cpu()
+        h_direct = m(r3m_ref.resize_center_crop_ref(x).to("cuda:0")).cpu()
+    assert h_branch.shape == (2, 512)
+    assert float((h_branch - h_direct).abs().max() / h_direct.abs().max()) < 1e-4
+
+
+def test_vectorised_box_sampler_matches_scalar_algorithm(hip):
+    """sample_boxes draws every box of a batch in a few tensor ops; its boxes must be the ones torchvision's get_params loop
+    (restated scalar form, r3m_amd.augment._sample_boxes_scalar) picks from the SAME per-try random numbers."""
+    from r3m_amd import augment
+    for (H, W) in ((256, 256), (224, 300), (100, 400)):
+        g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+        a = augment.sample_boxes(257, H, W, generator=g1)
+        b = augment._sample_boxes_scalar(257, H, W, generator=g2)
+        assert torch.equal(a, b), (H, W)

@@ -397,3 +397,19 @@ def test_sgd_matches_torch(hip, cfg):
         ref_buf = opt.state[pr]["momentum_buffer"]     # fp32 round-off level of the buffer's scale (fma contraction differs)
         torch.testing.assert_close(buf.cpu(), ref_buf, rtol=1e-6, atol=2e-7 * float(ref_buf.abs().max()))
     assert hip.r3m_sgd_step(pd.data_ptr(), gd.data_ptr(), None, n, 1e-2, 0.9, 0.0, 0.0, 0, 1, 1.0, st()) != 0   # momentum without a buffer
+
+
+def test_adam_matches_committed_golden(hip, golden_dir):
+    """G6: three fused-Adam steps against the committed torch.optim.Adam trajectory (tests/golden/adam.npz)."""
+    import os
+    from oracle import detgen
+    g = np.load(os.path.join(golden_dir, "adam.npz"))
+    n = 4096
+    p = torch.from_numpy(detgen.uniform("g6p", (n,), -1.0, 1.0)).to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(3):
+        gr = torch.from_numpy(detgen.uniform(f"g6g{i}", (n,), -1.0, 1.0) * np.float32(10.0 ** (i - 1))).to(DEV)
+        assert hip.r3m_adam_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, i + 1, 1.0, st()) == 0
+        np.testing.assert_allclose(p.cpu().numpy(), g[f"p_{i}"], rtol=1e-6, atol=2e-7)
+    np.testing.assert_allclose(m.cpu().numpy(), g["exp_avg"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), g["exp_avg_sq"], rtol=1e-6, atol=1e-12)

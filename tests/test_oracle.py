@@ -135,3 +135,47 @@ def test_kink_table_is_consistent_with_fp64_golden(golden_dir, size):
         nb = np.linalg.norm(g64["grad_" + lb + ".bias"].astype(np.float64))
         eff = [(abs(dg) / ng, db / nb) for dg, db in zip(k["dgamma"], k["dbeta"])]
         assert any(abs(a - 1.344e-3) < 2e-6 and abs(b - 1.807e-4) < 2e-7 for a, b in eff), eff
+
+
+@pytest.mark.parametrize("D", [512, 2048])
+def test_oracle_language_reward_matches_reference_golden(golden_dir, D):
+    """G4: the oracle's LanguageRewardRef against the reference's LanguageReward forward + backward at both head
+    widths — this is what pins the D = 2048 oracle that tests/test_gpu_fullsize.py checks the HIP head against."""
+    from oracle import detgen, r3m_ref
+    g = np.load(os.path.join(golden_dir, f"langrew_d{D}.npz"))
+    rew = r3m_ref.LanguageRewardRef(D, 1024, 768)
+    full = rew.state_dict()
+    sd = {}
+    for k, v in full.items():
+        fan_in = v.shape[1] if v.dim() == 2 else full[k.replace("bias", "weight")].shape[1]
+        sd[k] = torch.from_numpy(detgen.uniform("lr" + k, tuple(v.shape), -1.0 / np.sqrt(fan_in), 1.0 / np.sqrt(fan_in)))
+    rew.load_state_dict(sd)
+    B = 4
+    e0 = torch.from_numpy(np.maximum(detgen.uniform(f"g4e0_{D}", (B, D), -0.3, 1.0), 0)).requires_grad_(True)
+    eg = torch.from_numpy(np.maximum(detgen.uniform(f"g4eg_{D}", (B, D), -0.3, 1.0), 0)).requires_grad_(True)
+    le = torch.from_numpy(detgen.uniform(f"g4le_{D}", (B, 768), -0.6, 0.6))
+    score = rew(e0, eg, le)
+    (score * torch.from_numpy(detgen.uniform("g4cw", (B,), 0.5, 1.5))).sum().backward()
+    assert rel_err(score.detach().numpy(), g["score"])[0] < 1e-5
+    assert rel_err(e0.grad.numpy(), g["de0"])[0] < 1e-4 and rel_err(eg.grad.numpy(), g["deg"])[0] < 1e-4
+    for k, p in rew.named_parameters():
+        ref_n = float(g["gradnorm_" + k])
+        assert abs(float(p.grad.double().norm()) - ref_n) <= 1e-4 * max(ref_n, 1e-12), k
+
+
+def test_adam_golden_is_torch_adam(golden_dir):
+    """G6: the committed Adam trajectory (torch.optim.Adam, lr 1e-4, defaults — models_r3m.py:76) reproduces with the formula of
+    SURVEY.md §8(a) A11 evaluated in float64; the GPU test gates the fused HIP Adam against the same file."""
+    from oracle import detgen
+    g = np.load(os.path.join(golden_dir, "adam.npz"))
+    p = detgen.uniform("g6p", (4096,), -1.0, 1.0).astype(np.float64)
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for i in range(3):
+        gr = (detgen.uniform(f"g6g{i}", (4096,), -1.0, 1.0) * np.float32(10.0 ** (i - 1))).astype(np.float64)
+        m = 0.9 * m + 0.1 * gr
+        v = 0.999 * v + 0.001 * gr * gr
+        t = i + 1
+        p = p - 1e-4 / (1 - 0.9 ** t) * m / (np.sqrt(v) / np.sqrt(1 - 0.999 ** t) + 1e-8)
+        assert np.abs(p - g[f"p_{i}"]).max() < 2e-7
+    assert rel_err(m, g["exp_avg"])[0] < 1e-6 and rel_err(v, g["exp_avg_sq"])[0] < 1e-6
