@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--doaug", choices=["none", "rctraj", "rc"], default="none",
                     help="rctraj/rc: BASELINE configs[4] — every step starts from resident uint8 256x256 clips and runs the on-GPU "
                          "RandomResizedCrop(224) (csrc/augment.hip) inside the timed region")
+    ap.add_argument("--unfused-crop", action="store_true", help="with --doaug: run the stand-alone crop kernel (fp32 frames written, then "
+                                                                "read by the stem pre-pass) instead of cropping inside the stem pre-pass (A/B)")
     ap.add_argument("--encoder-only-frames", type=int, default=0,
                     help="> 0: the literal reading of 'bs=256': F frames through encoder forward + backward of sum|h| + Adam, no clip "
                          "structure / TCN loss (SURVEY.md §8(d) continuity point); the headline stays the 256-clip step")
@@ -133,7 +135,8 @@ def main():
         from r3m_amd import augment
         raw = torch.randint(0, 256, (B, 5, 3, 256, 256), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
         box_gen = torch.Generator().manual_seed(99 + rank)
-        get_frames = lambda: augment.random_resized_crop(raw, per_clip=(args.doaug == "rctraj"), generator=box_gen)
+        get_frames = lambda: augment.random_resized_crop(raw, per_clip=(args.doaug == "rctraj"), generator=box_gen,
+                                                         fused=not args.unfused_crop)
     langs = [""] * B
     if args.langweight > 0:   # frozen DistilBERT stand-in: [B,768] N(0,1)*0.3, all clips have language
         gl = torch.Generator(device=dev).manual_seed(4321 + rank)

@@ -56,6 +56,14 @@ int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, floa
                        int training, r3m_stream_t stream);
 /* dh: [frames, out_dim]. Runs stages [stage_begin, stage_end) in order; stage 0 must come first after a forward.
  * accumulate=0 overwrites grads, 1 adds to them. */
+/* The same forward fed from RAW clips through crop boxes: the rc / rctraj RandomResizedCrop(224) of the reference's loader
+ * (r3m/utils/data_loaders.py:47-50,88-102) resampled INSIDE the stem pre-pass — one gather-bilinear pass from uint8 (or float
+ * 0..255) frames [F,3,Hi,Wi] straight into the normalised stem image; the cropped fp32 frames are never materialised.
+ * boxes[f / frames_per_box] = {top, left, height, width}; frames_per_box = 5 (rctraj: one box per clip) or 1 (rc).
+ * Bit-identical to r3m_crop_resize followed by r3m_resnet_forward. */
+int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi,
+                            int Wi, const float* params, float* buffers, void* arena, float* h_out, int training,
+                            r3m_stream_t stream);
 int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
                         int stage_end, int accumulate, r3m_stream_t stream);
 

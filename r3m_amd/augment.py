@@ -92,11 +92,66 @@ def crop_resize(frames, boxes, frames_per_box, out_hw=(224, 224)):
     return out
 
 
-def random_resized_crop(batch, per_clip=True, generator=None):
-    """batch [B,5,3,H,W] -> [B,5,3,224,224]; per_clip=True is `rctraj` (one box per clip), False is `rc`."""
+class CroppedClips:
+    """Raw clips + crop boxes standing where the cropped frames [B,T,3,224,224] would stand. The encoder resamples the boxes
+    inside its stem pre-pass (r3m_resnet_forward_crop: uint8 -> normalised stem image in one gather pass), so the cropped fp32
+    frames — 0.6 MB each, written and read back in round 1 — never exist. Quacks enough like a tensor for Trainer.update
+    (`.shape`, `.reshape(B*T, 3, 224, 224)`) and the prefetcher (`.float()`, `.record_stream()`); `.materialize()` gives the
+    pixels (bit-identical to what the encoder sees)."""
+
+    def __init__(self, raw, boxes, frames_per_box, out_hw=(224, 224)):
+        if not raw.is_cuda:
+            raise RuntimeError("r3m_amd.augment: HIP kernel needs a CUDA/HIP tensor (no CPU fallback)")
+        if raw.dtype not in (torch.uint8, torch.float32):
+            raw = raw.float()
+        lead = raw.shape[:-3]
+        self.raw = raw.reshape(-1, *raw.shape[-3:]).contiguous()                       # [N,3,H,W]
+        self.boxes = boxes.to(device=raw.device, dtype=torch.int32).contiguous()
+        self.frames_per_box = int(frames_per_box)
+        assert self.boxes.shape[0] * self.frames_per_box == self.raw.shape[0] and self.raw.shape[1] == 3
+        self.out_hw = tuple(out_hw)
+        self.shape = torch.Size((*lead, 3, *self.out_hw))
+        self.device, self.dtype, self.is_cuda = raw.device, torch.float32, True
+
+    def dim(self):
+        return len(self.shape)
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        n = self.raw.shape[0]
+        if -1 in shape:
+            known = -math.prod(shape)
+            shape = tuple(n * 3 * self.out_hw[0] * self.out_hw[1] // known if d == -1 else d for d in shape)
+        if math.prod(shape) != math.prod(self.shape) or tuple(shape[-3:]) != (3, *self.out_hw):
+            raise ValueError(f"CroppedClips.reshape{shape}: only the leading (clip, frame) dimensions can be regrouped")
+        out = object.__new__(CroppedClips)
+        out.__dict__.update(self.__dict__)
+        out.shape = torch.Size(shape)
+        return out
+
+    def float(self):
+        return self
+
+    def contiguous(self):
+        return self
+
+    def record_stream(self, stream):
+        self.raw.record_stream(stream)
+        self.boxes.record_stream(stream)
+
+    def materialize(self):
+        return crop_resize(self.raw, self.boxes, self.frames_per_box, self.out_hw).reshape(self.shape)
+
+
+def random_resized_crop(batch, per_clip=True, generator=None, fused=False):
+    """batch [B,5,3,H,W] -> [B,5,3,224,224]; per_clip=True is `rctraj` (one box per clip), False is `rc`
+    (/root/reference/r3m/utils/data_loaders.py:88-102). fused=True returns a CroppedClips handle instead of pixels: the crop
+    then runs inside the encoder's stem pre-pass."""
     B, T = batch.shape[:2]
     H, W = batch.shape[-2:]
     boxes = sample_boxes(B if per_clip else B * T, H, W, generator=generator)
+    if fused:
+        return CroppedClips(batch, boxes, T if per_clip else 1)
     out = crop_resize(batch.reshape(B * T, *batch.shape[2:]), boxes, T if per_clip else 1)
     return out.reshape(B, T, *out.shape[1:])
 

@@ -5,6 +5,7 @@
 // is the crop + bilinear resize (align_corners=False, no antialias, as torchvision 0.8.2's tensor path) in one gather
 // pass, uint8 or float frames in, float 0..255 out: HBM-bound, one read of the box region + one write.
 #include "common.h"
+#include "augment_dev.h"
 
 namespace r3m {
 
@@ -23,21 +24,10 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const T* __restrict__ 
   // box = source region (top, left, height, width); without boxes: the whole frame
   const int* b = boxes ? boxes + (n / frames_per_box) * 4 : nullptr;
   const int top = b ? b[0] : 0, left = b ? b[1] : 0, bh = b ? b[2] : Hi, bw = b ? b[3] : Wi;
-  // ATen upsample_bilinear2d, align_corners=False: src = max(0, (dst + 0.5) * scale - 0.5), scale = in/out. The region is
-  // resized to full_Ho x full_Wo, of which this launch writes the Ho x Wo window at (dst_top, dst_left): crop-then-resize has
-  // window == everything, resize-then-centre-crop has region == everything.
-  const float sy = fmaxf(((float)(y + dst_top) + 0.5f) * ((float)bh / (float)full_Ho) - 0.5f, 0.f);
-  const float sx = fmaxf(((float)(x + dst_left) + 0.5f) * ((float)bw / (float)full_Wo) - 0.5f, 0.f);
-  const int y0 = (int)sy, x0 = (int)sx;
-  const int y1 = y0 + (y0 < bh - 1 ? 1 : 0), x1 = x0 + (x0 < bw - 1 ? 1 : 0);
-  const float ly = sy - (float)y0, lx = sx - (float)x0;
-  const float hy = 1.f - ly, hx = 1.f - lx;
+  // The region is resized to full_Ho x full_Wo, of which this launch writes the Ho x Wo window at (dst_top, dst_left):
+  // crop-then-resize has window == everything, resize-then-centre-crop has region == everything.
   const T* p = in + (n * C + c) * (long long)Hi * Wi;
-  const float v00 = (float)p[(long long)(top + y0) * Wi + left + x0] / 255.0f;
-  const float v01 = (float)p[(long long)(top + y0) * Wi + left + x1] / 255.0f;
-  const float v10 = (float)p[(long long)(top + y1) * Wi + left + x0] / 255.0f;
-  const float v11 = (float)p[(long long)(top + y1) * Wi + left + x1] / 255.0f;
-  out[idx] = (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11)) * 255.0f;
+  out[idx] = bilinear_sample(p, Wi, top, left, bh, bw, y, x, dst_top, dst_left, full_Ho, full_Wo);
 }
 
 static int launch_resample(const void* in, int in_is_u8, const int* boxes, float* out, long long N, int C, int Hi, int Wi, int Ho,

@@ -1,5 +1,6 @@
 // r3m_amd — extern "C" surface of libr3m_hip.so (declared in include/r3m_hip.h).
 #include "common.h"
+#include "augment_dev.h"
 #include "../../include/r3m_hip.h"
 #include <cstdarg>
 #include <cstdio>
@@ -105,6 +106,8 @@ Plan* plan_create(int size, int F, int dtype);
 int plan_dtype(Plan*);
 int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
                  hipStream_t s);
+int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, const float* params, float* bufs, float* arena,
+                     float* h_out, int training, hipStream_t s);
 int plan_backward(Plan& P, const float* dh, const float* params, float* grads, float* arena, int stage_begin, int stage_end,
                   int accumulate, int* gd_io, hipStream_t s);
 int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, const float* bias, int N, int Hi, int Wi, int Ci,
@@ -225,6 +228,13 @@ int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, floa
                        r3m_stream_t stream) {
   R3M_REQUIRE(h && x && params && buffers && arena && h_out, "resnet_forward: null argument");
   return plan_forward(*PLAN(h), x, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
+}
+int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi, int Wi,
+                            const float* params, float* buffers, void* arena, float* h_out, int training, r3m_stream_t stream) {
+  R3M_REQUIRE(h && frames && boxes && params && buffers && arena && h_out, "resnet_forward_crop: null argument");
+  R3M_REQUIRE(frames_per_box >= 1 && Hi >= 1 && Wi >= 1, "resnet_forward_crop: frames_per_box=%d, frames %dx%d", frames_per_box, Hi, Wi);
+  const FrameSource src{frames, frames_are_u8, boxes, frames_per_box, Hi, Wi};
+  return plan_forward_src(*PLAN(h), nullptr, &src, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
 }
 int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
                         int stage_end, int accumulate, r3m_stream_t stream) {

@@ -113,6 +113,9 @@ int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s);
 int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s);
+struct FrameSource;   // augment_dev.h: raw clips + crop boxes
+int launch_stem_prep_crop(const FrameSource& src, float* xn, int F, hipStream_t s);
+int launch_stem_prep16_crop(const FrameSource& src, void* xn16, int F, hipStream_t s);
 int launch_stem_fwd(const float* xn, const float* w147, void* y, float* stats, int F, int dt, hipStream_t s);
 size_t stem_wgrad_ws_floats();
 int launch_stem_wgrad(const float* xn, const void* dY, float* dw147, float* ws, int F, int accumulate, int dt, hipStream_t s);

@@ -24,6 +24,7 @@
 // with the MFMA stream; the tap table is a dword array in the kernarg segment (scalar loads).
 #include "common.h"
 #include "conv_dev.h"
+#include "augment_dev.h"
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -406,6 +407,162 @@ __global__ __launch_bounds__(256) void gather_gemm_glds2_kernel(const GatherGemm
 }
 
 // =====================================================================================================
+// gather-GEMM 128 x 128 with 16-wide K tiles (64-byte LDS rows) for launches whose main loop is SHORT: the expanding 1x1
+// convolutions (K = Cin = 64 / 128 / 256 against N = 4 Cin) and the 1x1 downsample convolutions. There a block's life is
+// prologue latency + 2-8 K steps + a 64 KB epilogue, and with the 64 KB of the 32-wide two-stage ring only two blocks share a
+// CU, so nothing hides the one's loads / stores behind the other's (measured round 1: 62.6 / 87 / 110 TFLOP/s for K = 64 / 128 /
+// 256 against 117 for the class; these launches sit at the HBM ridge — 25 FLOP/B for K = 64). With 16-wide tiles the ring is
+// 2 x 16 KB and the LDS footprint is the 34 KB epilogue slab: three to four blocks per CU (registers: 128 per lane).
+// Layout: rows of 16 floats = four 16-byte slots, slot XOR ((row >> 2) & 3) — a ds_read_b128 lane group (16 lanes, MI355X
+// guide) then touches 16 distinct slots of the 256-byte bank row; one DMA instruction lands 16 rows (lane -> row lane>>2,
+// slot lane&3; the swizzle is applied to the global source column). Fragments and MFMA order as in the 32-wide kernel
+// (k = 8g + 4h .. +3 per lane half h, groups g = 0, 1), so results are bit-identical to it.
+// =====================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void gather_gemm_k16_kernel(const GatherGemmParams p) {
+  constexpr int BM = 128, BN = 128, WM = 2, WN = 2;
+  constexpr int STAGE = (BM + BN) * 16;                  // floats per stage (16 KiB)
+  constexpr int SMEM = 4 * 32 * (64 + 4);                // the epilogue slab (8704 floats) >= the two stages (8192)
+  static_assert(SMEM >= 2 * STAGE, "ring must fit under the epilogue slab");
+  __shared__ __attribute__((aligned(128))) float smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s / WN, wn = wave_s % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // staging: a wave owns 32 A rows and 32 B rows = 2 + 2 DMA instructions of 16 rows per tile
+  const int srow = lane >> 2;
+  const int scol = ((lane & 3) ^ ((lane >> 4) & 3)) * 4;   // (row >> 2) & 3 == (lane >> 4) & 3: row = 32 w + 16 j + (lane >> 2)
+  const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  RowDesc ad[2];
+  unsigned arow_ok = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wave_s * 32 + j * 16 + srow;
+    ad[j] = decode_row(p, m);
+    if (m < p.M) arow_ok |= 1u << j;
+  }
+  const float* bptr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = min(n0 + wave_s * 32 + j * 16 + srow, p.Nc - 1);
+    bptr[j] = p.B + (long long)n * p.T * p.Ci + scol;
+  }
+  const int kpt = p.Ci >> 4;          // 16-wide tiles per tap (even: Ci is a multiple of 32)
+  const int hpt = kpt >> 1;
+  const int npairs = p.ntaps * hpt;
+
+  const float* pa[2];
+  const float* pb[2];
+  auto set_tap = [&](int pack) {
+    const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
+      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
+      const float* src = p.A + ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci + scol;
+      const unsigned long long msk = in ? ~0ull : 0ull;
+      pa[j] = reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(src) & msk) |
+                                             (reinterpret_cast<unsigned long long>(g_zero_line + scol) & ~msk));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pb[j] = bptr[j] + (long long)wt * p.Ci;
+  };
+  // stage STG, the instruction's immediate IMM (bytes) is added to BOTH addresses -> LDS destination pre-biased by -IMM
+  auto issue = [&](auto stg_c, auto imm_c) __attribute__((always_inline)) {
+    constexpr int STG = decltype(stg_c)::value, IMM = decltype(imm_c)::value;
+    float* la = smem + STG * STAGE + wave_s * 32 * 16 - IMM / 4;
+    float* lb = smem + STG * STAGE + BM * 16 + wave_s * 32 * 16 - IMM / 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[j],
+                                       (__attribute__((address_space(3))) void*)(la + j * 16 * 16), 16, IMM, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[j],
+                                       (__attribute__((address_space(3))) void*)(lb + j * 16 * 16), 16, IMM, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int xr = (lrow >> 2) & 3;
+  const float* fa[2];
+  const float* fb[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int go = ((2 * g + lh) ^ xr) * 4;
+    fa[g] = smem + (wm * 64 + lrow) * 16 + go;
+    fb[g] = smem + BM * 16 + (wn * 64 + lrow) * 16 + go;
+  }
+  auto mfma_tile = [&](auto stg_c) __attribute__((always_inline)) {
+    constexpr int STG = decltype(stg_c)::value;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const f32x4*>(fa[g] + STG * STAGE + t * 32 * 16);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const f32x4*>(fb[g] + STG * STAGE + t * 32 * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I64 = std::integral_constant<int, 64>;
+
+  int tap_n = 0, cp = 0;
+  if (npairs > 0) {
+    set_tap(p.tap[0]);
+    issue(I0{}, I0{});                                    // tile 0 -> stage 0
+  }
+  int pack_next = p.ntaps > 1 ? p.tap[1] : 0;
+  for (int pr = 0; pr < npairs; ++pr) {
+    // even tile (stage 0): issue the odd tile (same tap, next 16 channels: +64 B immediate) first, then the MFMAs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue(I1{}, I64{});
+    mfma_tile(I0{});
+    // odd tile (stage 1): issue the next pair's even tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pr + 1 < npairs) {
+      if (++cp == hpt) {
+        cp = 0;
+        ++tap_n;
+        set_tap(pack_next);
+        pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { pa[j] += 32; pb[j] += 32; }
+      }
+      issue(I0{}, I0{});
+    }
+    mfma_tile(I1{});
+  }
+  __syncthreads();
+  gg_epilogue<BM, BN, WM, WN, EPI, SMEM>(p, acc, smem, m0, n0, mt);
+}
+
+// =====================================================================================================
 // gather-GEMM, register staging (256x64 tiles for 64-channel layers; also the 128x128 fallback R3M_GG_GLDS=0).
 // Operand tiles live in LDS as [row][k] with a 36-float row stride (conflict-free b128 writes and fragment reads).
 // Single LDS stage; the next tile's global loads fly during the MFMA phase.
@@ -602,7 +759,13 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
+    // short main loop + wide output: single tap, K <= 256, N >= 2 K (expanding / downsample 1x1 convolutions) -> 16-wide K tiles
+    const bool short_loop = p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci && (p.Ci & 31) == 0 && R3M_ENV_INT("R3M_GG_K16", 1) != 0;
+    if (short_loop) {
+#define LAUNCH_K16(E) hipLaunchKernelGGL((gather_gemm_k16_kernel<E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_K16)
+#undef LAUNCH_K16
+    } else if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
 #define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_GLDS2)
 #undef LAUNCH_GLDS2
@@ -1045,6 +1208,40 @@ __global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict_
   float* o = xn + i * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) o[c] = (x[((f * 3 + c) * 224 + iy) * 224 + ix] / 255.0f - mean[c]) / sd[c];
+}
+
+// the same pre-pass reading the RAW clips through their crop boxes (rc / rctraj on the GPU): the cropped fp32
+// frames [F,3,224,224] are never written — one gather-bilinear pass from uint8 (or float) straight into the normalised image
+template <typename T>
+__global__ __launch_bounds__(256) void stem_prep_crop_kernel(const T* __restrict__ raw, const int* __restrict__ boxes,
+                                                              float* __restrict__ xn, long long total, int Hi, int Wi, int fpb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per (f, iy, ix)
+  if (i >= total) return;
+  const int ix = (int)(i % 224);
+  const long long t = i / 224;
+  const int iy = (int)(t % 224);
+  const long long f = t / 224;
+  const int* b = boxes + (f / fpb) * 4;
+  const int top = b[0], left = b[1], bh = b[2], bw = b[3];
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  float* o = xn + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224);
+    o[c] = (v / 255.0f - mean[c]) / sd[c];
+  }
+}
+
+int launch_stem_prep_crop(const FrameSource& src, float* xn, int F, hipStream_t s) {
+  const long long total = (long long)F * 224 * 224;
+  if (src.is_u8)
+    hipLaunchKernelGGL((stem_prep_crop_kernel<unsigned char>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                       static_cast<const unsigned char*>(src.frames), src.boxes, xn, total, src.Hi, src.Wi, src.frames_per_box);
+  else
+    hipLaunchKernelGGL((stem_prep_crop_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                       static_cast<const float*>(src.frames), src.boxes, xn, total, src.Hi, src.Wi, src.frames_per_box);
+  return check_launch("stem_prep_crop");
 }
 
 int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s) {

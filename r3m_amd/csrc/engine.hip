@@ -10,6 +10,7 @@
 // frame count F); parameters and gradients are two flat fp32 buffers in torchvision parameter order with conv weights
 // stored OHWI (= logical OIHW tensors with channels_last strides, so state-dict interchange needs no copy kernels).
 #include "common.h"
+#include "augment_dev.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -363,8 +364,17 @@ static int conv_bn(Ctx& c, const ConvSpec& L, const float* X) {
   return conv_bn_coeffs(c, L, X, fwd_weights(c, L), L.Ci, L.k, L.stride, L.pad, L.Hi, L.Wi, c.P.F);
 }
 
+int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, const float* params, float* bufs, float* arena,
+                     float* h_out, int training, hipStream_t s);
 int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs, float* arena, float* h_out, int training,
                  hipStream_t s) {
+  return plan_forward_src(P, x_nchw, nullptr, params, bufs, arena, h_out, training, s);
+}
+
+// frames come either as [F,3,224,224] fp32 0..255 (x_nchw) or as raw clips + crop boxes (crop: rc / rctraj resampled inside the
+// stem pre-pass)
+int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, const float* params, float* bufs, float* arena,
+                     float* h_out, int training, hipStream_t s) {
   Ctx c{P, params, nullptr, bufs, arena, s, training, 0, P.dtype};
   P.last_training = training;
   const int F = P.F;
@@ -374,8 +384,14 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
   const ConvSpec& L0 = P.convs[0];
   // normalised, channel-interleaved copy of the frames (0.6 MB/frame): read by the stem forward now and by its weight
   // gradient in backward (the caller's tensor may be gone by then)
-  if (dt == DT_BF16) TRY(launch_stem_prep16(x_nchw, arena + P.col_off, F, s));
-  else TRY(launch_stem_prep(x_nchw, arena + P.col_off, F, s));
+  if (crop) {
+    if (dt == DT_BF16) TRY(launch_stem_prep16_crop(*crop, arena + P.col_off, F, s));
+    else TRY(launch_stem_prep_crop(*crop, arena + P.col_off, F, s));
+  } else if (dt == DT_BF16) {
+    TRY(launch_stem_prep16(x_nchw, arena + P.col_off, F, s));
+  } else {
+    TRY(launch_stem_prep(x_nchw, arena + P.col_off, F, s));
+  }
   {
     float* partial = arena + P.partial_off;
     double* acc = reinterpret_cast<double*>(arena + P.acc_off);

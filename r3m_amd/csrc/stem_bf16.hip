@@ -14,6 +14,7 @@
 //             patch operand is 8 pixels at a 12-byte stride -> eight ds_read_u16 per operand, packed in registers.
 #include "common.h"
 #include "conv_dev.h"
+#include "augment_dev.h"
 #include <cstring>
 
 namespace r3m {
@@ -50,6 +51,49 @@ __global__ __launch_bounds__(256) void stem_prep16_kernel(const float* __restric
     o[e] = (bf16_t)v;
   }
   *reinterpret_cast<bf16x8*>(xn16 + i * 8) = o;
+}
+
+// the same image built from the RAW clips through their crop boxes (see stem_prep_crop_kernel in conv.hip)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_prep16_crop_kernel(const T* __restrict__ raw, const int* __restrict__ boxes,
+                                                                bf16_t* __restrict__ xn16, long long total, int Hi, int Wi, int fpb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per 8-element chunk
+  if (i >= total) return;
+  const int ch = (int)(i % (XN_ROW / 8));
+  long long t = i / (XN_ROW / 8);
+  const int r = (int)(t % XN_ROWS);
+  const long long f = t / XN_ROWS;
+  const int* b = boxes + (f / fpb) * 4;
+  const int top = b[0], left = b[1], bh = b[2], bw = b[3];
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  bf16x8 o;
+  const int iy = r - 3;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = ch * 8 + e - 9;
+    float v = 0.f;
+    if ((unsigned)iy < 224u && (unsigned)idx < 672u) {
+      const int ix = idx / 3, c = idx - ix * 3;
+      const float px = bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224);
+      v = (px / 255.0f - mean[c]) / sd[c];
+    }
+    o[e] = (bf16_t)v;
+  }
+  *reinterpret_cast<bf16x8*>(xn16 + i * 8) = o;
+}
+
+int launch_stem_prep16_crop(const FrameSource& src, void* xn16, int F, hipStream_t s) {
+  const long long total = (long long)F * XN_ROWS * (XN_ROW / 8);
+  if (src.is_u8)
+    hipLaunchKernelGGL((stem_prep16_crop_kernel<unsigned char>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                       static_cast<const unsigned char*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
+                       src.frames_per_box);
+  else
+    hipLaunchKernelGGL((stem_prep16_crop_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                       static_cast<const float*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
+                       src.frames_per_box);
+  return check_launch("stem_prep16_crop");
 }
 
 int launch_stem_prep16(const float* x_nchw, void* xn16, int F, hipStream_t s) {

@@ -49,8 +49,8 @@ class _EncoderFn(torch.autograd.Function):
     """h = encoder(x). Backward writes parameter gradients straight into the module's flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, anchor, module, training):
-        h = module._run_forward(x, training)
+    def forward(ctx, x, anchor, module, training, crop=None):
+        h = module._run_forward(x, training, crop)
         ctx.module = module
         ctx.generation = module._generation
         return h
@@ -58,7 +58,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         ctx.module._run_backward(dh.contiguous(), ctx.generation)
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 PRECISIONS = {"fp32": 0, "bf16": 1}   # R3M_DT_F32 / R3M_DT_BF16 (include/r3m_hip.h)
@@ -261,18 +261,28 @@ class HipResNet(nn.Module):
         for p in self.parameters():      # gradients were views of the dropped flat buffer
             p.grad = None
 
-    def _run_forward(self, x, training):
+    def _run_forward(self, x, training, crop=None):
+        """x: [F,3,224,224] fp32 frames, or None with crop = augment.CroppedClips (raw clips + boxes, resampled in the stem pre-pass)."""
         L = _lib.lib()
-        F = x.shape[0]
+        src = crop.raw if crop is not None else x
+        F = src.shape[0]
         h = self._plan(F)
         need = L.r3m_resnet_arena_bytes(h)
-        if self._arena is None or self._arena.numel() < need or self._arena.device != x.device:
+        if self._arena is None or self._arena.numel() < need or self._arena.device != src.device:
             self._arena = None  # release first: the arena is the dominant HBM allocation
-            self._arena = torch.empty(need, dtype=torch.uint8, device=x.device)
-        out = torch.empty((F, self.outdim), dtype=torch.float32, device=x.device)
-        with _lib.on(x):
-            _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
-                                            out.data_ptr(), 1 if training else 0, _lib.stream_ptr(x.device)), "resnet_forward")
+            self._arena = torch.empty(need, dtype=torch.uint8, device=src.device)
+        out = torch.empty((F, self.outdim), dtype=torch.float32, device=src.device)
+        with _lib.on(src):
+            if crop is not None:
+                _lib.check(L.r3m_resnet_forward_crop(h, crop.raw.data_ptr(), 1 if crop.raw.dtype == torch.uint8 else 0,
+                                                     crop.boxes.data_ptr(), crop.frames_per_box, crop.raw.shape[-2], crop.raw.shape[-1],
+                                                     self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
+                                                     out.data_ptr(), 1 if training else 0, _lib.stream_ptr(src.device)),
+                           "resnet_forward_crop")
+            else:
+                _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(),
+                                                self._arena.data_ptr(), out.data_ptr(), 1 if training else 0,
+                                                _lib.stream_ptr(x.device)), "resnet_forward")
         if training:
             self._flat_nbt += 1
         self._generation += 1
@@ -302,16 +312,21 @@ class HipResNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("r3m_amd: the encoder runs on MI355X through libr3m_hip.so only; got a CPU tensor "
                                "(no CPU / eager fallback exists — the CPU oracle lives under oracle/ for tests)")
-        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+        from .augment import CroppedClips
+        crop = x if isinstance(x, CroppedClips) else None
+        if crop is not None and tuple(crop.out_hw) != (224, 224):
+            raise ValueError(f"CroppedClips must resample to 224x224, got {crop.out_hw}")
+        if crop is None and (x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224)):
             raise ValueError(f"expected [F,3,224,224], got {tuple(x.shape)}")
         self._ensure()
         if self._flat_p.device != x.device:
             raise RuntimeError(f"encoder parameters on {self._flat_p.device}, input on {x.device}")
-        x = x.contiguous()
-        if x.dtype != torch.float32:
-            x = x.float()
+        if crop is None:
+            x = x.contiguous()
+            if x.dtype != torch.float32:
+                x = x.float()
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
             anchor = next(self.parameters())
-            return _EncoderFn.apply(x, anchor, self, self.training)
-        return self._run_forward(x, self.training)
+            return _EncoderFn.apply(None if crop is not None else x, anchor, self, self.training, crop)
+        return self._run_forward(None if crop is not None else x, self.training, crop)

@@ -74,7 +74,8 @@ class Workspace:
     def _gpu_transform(doaug):
         if doaug in ("rc", "rctraj"):
             from .augment import random_resized_crop
-            return lambda x: random_resized_crop(x, per_clip=(doaug == "rctraj"))
+            # boxes only: the resample itself happens inside the encoder's stem pre-pass (augment.CroppedClips)
+            return lambda x: random_resized_crop(x, per_clip=(doaug == "rctraj"), fused=True)
         return None
 
     def train(self):

@@ -82,3 +82,40 @@ def test_vectorised_box_sampler_matches_scalar_algorithm(hip):
         a = augment.sample_boxes(257, H, W, generator=g1)
         b = augment._sample_boxes_scalar(257, H, W, generator=g2)
         assert torch.equal(a, b), (H, W)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("per_clip,dtype", [(True, torch.uint8), (False, torch.uint8), (True, torch.float32)])
+def test_crop_inside_the_stem_prepass_equals_crop_then_forward(hip, precision, per_clip, dtype):
+    """SURVEY.md §8(f)1 as written: ONE gather-bilinear pass from the uint8 clips into the normalised stem image
+    (r3m_resnet_forward_crop via augment.CroppedClips). Must give the SAME embeddings and parameter gradients as the stand-alone
+    crop kernel followed by the ordinary forward — both run the same float operations (csrc/augment_dev.h) — for rctraj (one box
+    per clip) and rc (one per frame), uint8 and float clips, fp32 and bf16 plans, train and eval mode."""
+    import numpy as np
+    from oracle import detgen
+    from r3m_amd import R3M, augment
+    B, T, H, W = 3, 5, 256, 320
+    g = torch.Generator().manual_seed(21)
+    raw = torch.randint(0, 256, (B, T, 3, H, W), generator=g, dtype=torch.uint8).to("cuda:0").to(dtype)
+    boxes = augment.sample_boxes(B if per_clip else B * T, H, W, generator=g)
+    boxes[0] = torch.tensor([H - 9, W - 6, 9, 6], dtype=torch.int32)       # tiny corner box: up-sampling + edge clamps
+    clips = augment.CroppedClips(raw, boxes, T if per_clip else 1)
+    assert clips.shape == (B, T, 3, 224, 224) and clips.reshape(B * T, 3, 224, 224).shape == (B * T, 3, 224, 224)
+    pixels = clips.materialize()
+    assert pixels.shape == (B, T, 3, 224, 224)
+    m = R3M("cuda", 1e-4, 1024, size=18, langweight=0.0, tcnweight=1.0, precision=precision)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()})
+    m = m.to("cuda:0")
+    for training in (False, True):
+        m.train(training)
+        res = []
+        for inp in (pixels.reshape(B * T, 3, 224, 224), clips.reshape(B * T, 3, 224, 224)):
+            m.encoder_opt.zero_grad()
+            h = m(inp)
+            (h * torch.linspace(0.5, 1.5, h.shape[1], device=h.device)).sum().backward()
+            res.append((h.detach().clone(), m.convnet.flat_grads().clone()))
+        assert torch.equal(res[0][0], res[1][0]), f"embeddings differ ({precision}, training={training})"
+        assert torch.equal(res[0][1], res[1][1]), f"gradients differ ({precision}, training={training})"
+    with pytest.raises(ValueError):
+        clips.reshape(B * T * 3, 224, 224)

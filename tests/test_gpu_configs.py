@@ -188,7 +188,8 @@ def test_config4_resnet34_bf16_rctraj_full_size(hip):
     losses = []
     for it in range(2):
         torch.manual_seed(100 + it)
-        frames = augment.random_resized_crop(raw, per_clip=True, generator=box_gen)
+        frames = augment.random_resized_crop(raw, per_clip=True, generator=box_gen, fused=True)   # boxes only: crop in the stem pre-pass
+        assert isinstance(frames, augment.CroppedClips) and frames.shape == (B, 5, 3, 224, 224)
         met, _ = tr.update(net, (frames, [""] * B), it)
         assert all(np.isfinite(v) for v in met.values()), met
         losses.append(met["full_loss"])
