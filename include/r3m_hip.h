@@ -145,6 +145,11 @@ int r3m_stem_conv_wgrad_dt(const float* xn, const void* dy, float* dw_ohwi, void
  * weight gradient (dy bf16, dw fp32 [64,7,7,3]) stage their operands by plain contiguous copies. Same call sites as r3m_stem_*. */
 size_t r3m_stem_xn16_bytes(int frames);
 int r3m_stem_prep_bf16(const float* x_nchw, void* xn16, int frames, r3m_stream_t stream);
+/* The same pre-pass reading RAW clips through crop boxes (what r3m_resnet_forward_crop runs first): frames [F,3,Hi,Wi] uint8 or
+ * float 0..255, boxes[f / frames_per_box] = {top, left, height, width}; dtype R3M_DT_F32 writes xn (layout of r3m_stem_prep),
+ * R3M_DT_BF16 writes xn16 (layout of r3m_stem_prep_bf16). Bit-identical to r3m_crop_resize followed by r3m_stem_prep[_bf16]. */
+int r3m_stem_prep_crop(const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi, int Wi, void* xn_out,
+                       int F, int dtype, r3m_stream_t stream);
 int r3m_stem_conv_fwd_bf16(const void* xn16, const float* w_ohwi, void* y, float* stats, int frames, r3m_stream_t stream);
 size_t r3m_stem_conv_wgrad_bf16_workspace_bytes(void);
 int r3m_stem_conv_wgrad_bf16(const void* xn16, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int frames,

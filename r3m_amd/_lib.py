@@ -71,6 +71,7 @@ SIGNATURES = {
     "r3m_stem_conv_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_f]),
     "r3m_stem_xn16_bytes": (c_sz, [c_i]),
     "r3m_stem_prep_bf16": (c_i, [c_f, c_f, c_i, c_f]),
+    "r3m_stem_prep_crop": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_i, c_f]),
     "r3m_stem_conv_fwd_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f]),
     "r3m_stem_conv_wgrad_bf16_workspace_bytes": (c_sz, []),
     "r3m_stem_conv_wgrad_bf16": (c_i, [c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_f]),

@@ -11,7 +11,12 @@ pids=()
 SRCS="conv conv_bf16 stem_bf16 bn loss adam lang augment engine capi"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.h" -nt "$OBJ/$f.o" ] || [ "$HERE/conv_dev.h" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/r3m_hip.h" -nt "$OBJ/$f.o" ]; then
+  stale=0
+  [ -f "$OBJ/$f.o" ] || stale=1
+  for dep in "$HERE/$f.hip" "$HERE"/*.h "$HERE/../../include/r3m_hip.h" "$HERE/build.sh"; do
+    [ "$dep" -nt "$OBJ/$f.o" ] && stale=1
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi

@@ -329,6 +329,14 @@ int r3m_stem_prep_bf16(const float* x, void* xn16, int frames, r3m_stream_t stre
   R3M_REQUIRE(x && xn16, "stem_prep_bf16: null argument");
   return launch_stem_prep16(x, xn16, frames, S(stream));
 }
+int r3m_stem_prep_crop(const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi, int Wi, void* xn_out, int F,
+                       int dtype, r3m_stream_t stream) {
+  R3M_REQUIRE(frames && boxes && xn_out, "stem_prep_crop: null argument");
+  R3M_REQUIRE(frames_per_box >= 1 && Hi >= 1 && Wi >= 1 && F >= 1, "stem_prep_crop: frames_per_box=%d, %d frames of %dx%d", frames_per_box, F, Hi, Wi);
+  if (check_dt(dtype, "stem_prep_crop")) return 1;
+  const FrameSource src{frames, frames_are_u8, boxes, frames_per_box, Hi, Wi};
+  return dtype == DT_BF16 ? launch_stem_prep16_crop(src, xn_out, F, S(stream)) : launch_stem_prep_crop(src, static_cast<float*>(xn_out), F, S(stream));
+}
 int r3m_stem_conv_fwd_bf16(const void* xn16, const float* w_ohwi, void* y, float* stats, int frames, r3m_stream_t stream) {
   R3M_REQUIRE(xn16 && w_ohwi && y, "stem_conv_fwd_bf16: null argument");
   return launch_stem_fwd16(xn16, w_ohwi, y, stats, frames, S(stream));

@@ -1203,11 +1203,9 @@ __global__ __launch_bounds__(256) void stem_prep_kernel(const float* __restrict_
   const long long t = i / 224;
   const int iy = (int)(t % 224);
   const long long f = t / 224;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
   float* o = xn + i * 3;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = (x[((f * 3 + c) * 224 + iy) * 224 + ix] / 255.0f - mean[c]) / sd[c];
+  for (int c = 0; c < 3; ++c) o[c] = stem_normalize(x[((f * 3 + c) * 224 + iy) * 224 + ix], c);
 }
 
 // the same pre-pass reading the RAW clips through their crop boxes (rc / rctraj on the GPU): the cropped fp32
@@ -1223,14 +1221,10 @@ __global__ __launch_bounds__(256) void stem_prep_crop_kernel(const T* __restrict
   const long long f = t / 224;
   const int* b = boxes + (f / fpb) * 4;
   const int top = b[0], left = b[1], bh = b[2], bw = b[3];
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
   float* o = xn + i * 3;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v = bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224);
-    o[c] = (v / 255.0f - mean[c]) / sd[c];
-  }
+  for (int c = 0; c < 3; ++c)
+    o[c] = stem_normalize(bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224), c);
 }
 
 int launch_stem_prep_crop(const FrameSource& src, float* xn, int F, hipStream_t s) {

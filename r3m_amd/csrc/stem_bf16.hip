@@ -36,8 +36,6 @@ __global__ __launch_bounds__(256) void stem_prep16_kernel(const float* __restric
   long long t = i / (XN_ROW / 8);
   const int r = (int)(t % XN_ROWS);
   const long long f = t / XN_ROWS;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
   bf16x8 o;
   const int iy = r - 3;
 #pragma unroll
@@ -46,7 +44,7 @@ __global__ __launch_bounds__(256) void stem_prep16_kernel(const float* __restric
     float v = 0.f;
     if ((unsigned)iy < 224u && (unsigned)idx < 672u) {
       const int ix = idx / 3, c = idx - ix * 3;
-      v = (x[((f * 3 + c) * 224 + iy) * 224 + ix] / 255.0f - mean[c]) / sd[c];
+      v = stem_normalize(x[((f * 3 + c) * 224 + iy) * 224 + ix], c);
     }
     o[e] = (bf16_t)v;
   }
@@ -65,8 +63,6 @@ __global__ __launch_bounds__(256) void stem_prep16_crop_kernel(const T* __restri
   const long long f = t / XN_ROWS;
   const int* b = boxes + (f / fpb) * 4;
   const int top = b[0], left = b[1], bh = b[2], bw = b[3];
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
   bf16x8 o;
   const int iy = r - 3;
 #pragma unroll
@@ -75,8 +71,7 @@ __global__ __launch_bounds__(256) void stem_prep16_crop_kernel(const T* __restri
     float v = 0.f;
     if ((unsigned)iy < 224u && (unsigned)idx < 672u) {
       const int ix = idx / 3, c = idx - ix * 3;
-      const float px = bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224);
-      v = (px / 255.0f - mean[c]) / sd[c];
+      v = stem_normalize(bilinear_sample(raw + (f * 3 + c) * (long long)Hi * Wi, Wi, top, left, bh, bw, iy, ix, 0, 0, 224, 224), c);
     }
     o[e] = (bf16_t)v;
   }

@@ -8,7 +8,9 @@ SRC="$ROOT/r3m_amd/csrc"; OBJ="$ROOT/build/obj_probes"; OUT="$ROOT/r3m_amd/lib/v
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DR3M_PROBES $*"
 pids=()
 for f in conv conv_bf16 stem_bf16 bn loss adam lang augment engine capi; do
-  if [ ! -f "$OBJ/$f.o" ] || [ "$SRC/$f.hip" -nt "$OBJ/$f.o" ] || [ "$SRC/common.h" -nt "$OBJ/$f.o" ] || [ "$SRC/conv_dev.h" -nt "$OBJ/$f.o" ]; then
+  stale=0; [ -f "$OBJ/$f.o" ] || stale=1
+  for dep in "$SRC/$f.hip" "$SRC"/*.h "$ROOT/include/r3m_hip.h"; do [ "$dep" -nt "$OBJ/$f.o" ] && stale=1; done
+  if [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" & pids+=($!)
   fi
 done

@@ -58,15 +58,20 @@ def group(k):
     return k
 
 
+dur_norm = {short_name(k): v for k, v in dur.items()}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for k, cs in cnt.items():
     gk = group(k)
     for c, (n, s) in cs.items():
         agg[gk][c] += s
         agg[gk]["n_" + c] += n
-    if k in dur:
-        agg[gk]["calls"] += dur[k][0]
-        agg[gk]["time_us"] += dur[k][0] * dur[k][1]
+    # the counter CSV keeps mangled names for kernels with bf16 arguments (the tracer's demangler does not know DF16b) while the
+    # duration CSV (tools/rocpd_stats.py) already shortened them: join on the normalised name (round 1 looked up the raw key and
+    # every bn_*16 row came out with avg_us = 0)
+    d = dur.get(k) or dur_norm.get(short_name(k))
+    if d:
+        agg[gk]["calls"] += d[0]
+        agg[gk]["time_us"] += d[0] * d[1]
 
 rows = []
 for k, a in agg.items():
