@@ -75,7 +75,7 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
         worst_hip = max(worst_hip, abs(got - n64) / max(n64, 1e-12))
         worst_cpu = max(worst_cpu, abs(n32 - n64) / max(n64, 1e-12))
     report(f"r{size} grad-norm worst rel vs fp64: hip {worst_hip:.3e}  reference-cpu-fp32 {worst_cpu:.3e}")
-    assert worst_hip <= max(4.0 * worst_cpu, 1e-3)
+    assert worst_hip <= max(4.0 * worst_cpu, 1e-4)   # no blanket floor: the reference-fp32 error of the same tensors sets the scale
     # Last BatchNorm: its gradients are gated UP TO ReLU decisions of the last block on elements whose float64 pre-activation lies
     # within 2e-4 of zero (tests/golden/encoder_r*_kink.npz). VERDICT r1 weak #3: ResNet-34's d(gamma) sat 1.3e-3 from float64
     # while the reference's CPU fp32 sat at 1e-6 — that is ONE element (z = +3.4e-5 in float64, decided <= 0 by the fp32 forward
