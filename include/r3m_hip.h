@@ -134,6 +134,18 @@ int r3m_conv2d_fwd_dt(const void* x, const void* w_ohwi, void* y, float* stats, 
                       int stride, int pad, int dtype, r3m_stream_t stream);
 int r3m_conv2d_dgrad_dt(const void* dy, const float* w_ohwi, void* dx, void* workspace, size_t workspace_bytes, int N, int Hi,
                         int Wi, int Ci, int Co, int k, int stride, int pad, int dtype, r3m_stream_t stream);
+/* dgrad whose epilogue ALSO emits the first pass of the consumer BatchNorm's backward (what the engine runs for every BatchNorm
+ * whose dz has one producing dgrad): dx [N,Hi,Wi,Ci] is the gradient entering BatchNorm(+ReLU) with pre-normalisation input bn_y
+ * (same shape / dtype as dx) — optionally plus a masked residual gradient (dx = dgrad + residual_grad * [residual_bits], the
+ * join at a block input). partials [r3m_conv2d_dgrad_bnred_rows][2][Ci] (fp32): per 64 result rows, sum(g) and
+ * sum(g * (y - mean)) with g = dx * [mask]; mask = bn_bits (1 bit per element of the BatchNorm's block output) or, when
+ * bn_bits is NULL, recomputed as fma(y, bn_scale, bn_shift) > 0. Equals r3m_bn_bwd's reduce pass on the stored dx
+ * (replaces torch's batch_norm_backward reduction under the ResNet graph, call site trainer.py:157). */
+int r3m_conv2d_dgrad_bnred_rows(int N, int Hi, int Wi, int stride);
+int r3m_conv2d_dgrad_bnred_dt(const void* dy, const float* w_ohwi, void* dx, void* workspace, size_t workspace_bytes, int N, int Hi,
+                              int Wi, int Ci, int Co, int k, int stride, int pad, const void* residual_grad,
+                              const unsigned* residual_bits, const void* bn_y, const unsigned* bn_bits, const float* bn_scale,
+                              const float* bn_shift, const float* bn_mean, float* partials, int dtype, r3m_stream_t stream);
 size_t r3m_conv2d_wgrad_workspace_bytes_dt(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dtype);
 int r3m_conv2d_wgrad_dt(const void* x, const void* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int N, int Hi,
                         int Wi, int Ci, int Co, int k, int stride, int pad, int accumulate, int dtype, r3m_stream_t stream);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "r3m_convert_bf16": (c_i, [c_f, c_f, c_ll, c_f]),
     "r3m_conv2d_fwd_dt": (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 9 + [c_f]),
     "r3m_conv2d_dgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 9 + [c_f]),
+    "r3m_conv2d_dgrad_bnred_rows": (c_i, [c_i] * 4),
+    "r3m_conv2d_dgrad_bnred_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 8 + [c_f] * 8 + [c_i, c_f]),
     "r3m_conv2d_wgrad_workspace_bytes_dt": (c_sz, [c_i] * 9),
     "r3m_conv2d_wgrad_dt": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 10 + [c_f]),
     "r3m_stem_conv_fwd_dt": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f]),

@@ -509,10 +509,12 @@ int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbit
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
                                                                int use_batch_stats, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ c1,
-                                                               float* __restrict__ c2, int accumulate, int C) {
+                                                               float* __restrict__ c2, int accumulate, int C,
+                                                               const float* __restrict__ second_sum_scale) {
   int c;
   double sg, sgy;
   if (!slice_totals(acc, S, C, &c, &sg, &sgy)) return;
+  if (second_sum_scale) sgy *= (double)second_sum_scale[c];    // EPI_BNRED partials carry sum(g (y - mean)): x invstd = sum(g yhat)
   const float db = (float)sg, dg = (float)sgy;
   dbeta[c] = accumulate ? dbeta[c] + db : db;
   dgamma[c] = accumulate ? dgamma[c] + dg : dg;
@@ -521,9 +523,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
-                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s) {
+                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s,
+                                const float* second_sum_scale) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows),
-                     1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C);
+                     1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C, second_sum_scale);
   return check_launch("bn_bwd_finalize");
 }
 

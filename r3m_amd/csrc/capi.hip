@@ -277,6 +277,33 @@ int r3m_conv2d_dgrad_dt(const void* dy, const float* w, void* dx, void* ws, size
   else if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
   return conv_dgrad_launch(FP(dy), Wt, FPM(dx), nullptr, nullptr, nullptr, N, Hi, Wi, Ci, Co, k, stride, pad, 0, dtype, S(stream));
 }
+int r3m_conv2d_dgrad_bnred_rows(int N, int Hi, int Wi, int stride) {
+  if (stride == 1) return bnred_partial_rows((long long)N * Hi * Wi);
+  int rows = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int Hg = (Hi - py + 1) / 2, Wg = (Wi - px + 1) / 2;
+      if (Hg > 0 && Wg > 0) rows += bnred_partial_rows((long long)N * Hg * Wg);
+    }
+  return rows;
+}
+int r3m_conv2d_dgrad_bnred_dt(const void* dy, const float* w, void* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
+                              int k, int stride, int pad, const void* residual_grad, const unsigned* residual_bits, const void* bn_y,
+                              const unsigned* bn_bits, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                              float* partials, int dtype, r3m_stream_t stream) {
+  if (check_dt(dtype, "conv2d_dgrad_bnred")) return 1;
+  R3M_REQUIRE(dy && w && dx && ws && bn_y && bn_mean && partials, "conv2d_dgrad_bnred: null argument");
+  R3M_REQUIRE(bn_bits || (bn_scale && bn_shift), "conv2d_dgrad_bnred: pass the mask bits or scale + shift to recompute the mask");
+  R3M_REQUIRE(!residual_grad || residual_bits, "conv2d_dgrad_bnred: a residual gradient needs its mask bits");
+  R3M_REQUIRE(!(k == 1 && stride == 2), "conv2d_dgrad_bnred: 1x1 stride-2 (parity classes without taps) is not supported");
+  R3M_REQUIRE(ws_bytes >= r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k), "conv2d_dgrad_bnred: workspace too small");
+  float* Wt = static_cast<float*>(ws);
+  if (dtype == DT_BF16) { if (int e = launch_transpose_w_bf16(w, Wt, Co, k * k, Ci, S(stream))) return e; }
+  else if (int e = launch_transpose_w(w, Wt, Co, k * k, Ci, S(stream))) return e;
+  BnRedArgs br{FP(bn_y), bn_bits, bn_scale, bn_shift, bn_mean, partials, 0};
+  return conv_dgrad_launch_br(FP(dy), Wt, FPM(dx), FP(residual_grad), nullptr, residual_bits, N, Hi, Wi, Ci, Co, k, stride, pad,
+                              residual_grad ? EPI_MASKED_ADD : 0, dtype, &br, S(stream));
+}
 int r3m_conv2d_dgrad(const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co,
                      int k, int stride, int pad, r3m_stream_t stream) {
   return r3m_conv2d_dgrad_dt(dy, w, dx, ws, ws_bytes, N, Hi, Wi, Ci, Co, k, stride, pad, DT_F32, stream);

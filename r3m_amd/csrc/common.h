@@ -51,7 +51,14 @@ enum : int {
   EPI_BIAS       = 8,   // out = acc + bias[col]
   EPI_RELU       = 16,  // out = max(out, 0)
   EPI_MASK_OUT   = 32,  // out = (add1 > 0) ? acc : 0        (ReLU backward fused into a Linear dgrad)
+  EPI_BNRED      = 64,  // dgrad only: the result IS the gradient dz entering a BatchNorm(+ReLU) whose pre-normalisation output is
+                        // bn_y — also emit that BatchNorm's backward partials per 64 result rows: sum(g), sum(g * (y - mean)),
+                        // g = dz * [relu mask] (mask: bn_bits, or recomputed as fma(y, bn_scale, bn_shift) > 0). Replaces the
+                        // stand-alone first pass of BatchNorm backward (one read of dz and of y saved per layer).
 };
+
+// rows of the EPI_BNRED partial buffer one launch writes ([rows][2][Nc] floats): one per 64 GEMM rows, tile-independent
+static inline int bnred_partial_rows(long long M) { return (int)((M + 63) / 64); }
 
 constexpr int MAX_TAPS = 49;
 
@@ -67,7 +74,12 @@ struct GatherGemmParams {
   const float* add1;   // EPI_MASKED_ADD / EPI_MASK_OUT: mask source (post-ReLU activation), same shape as out
   const unsigned* addbits;  // EPI_MASKED_ADD: optional 1-bit/element ReLU mask of that activation (used instead of add1)
   const float* bias;   // EPI_BIAS: [Nc]
-  float* stats;        // EPI_STATS: [gridM][2][Nc]
+  float* stats;        // EPI_STATS: [gridM][2][Nc];  EPI_BNRED: [bnred_partial_rows(M)][2][Nc]
+  const float* bn_y;        // EPI_BNRED: the consumer BatchNorm's input (conv output), same shape / storage type as out
+  const unsigned* bn_bits;  // EPI_BNRED: 1-bit ReLU mask of the BatchNorm(+residual) output, or null -> recompute from bn_y
+  const float* bn_scale;    // EPI_BNRED: [Nc] forward coefficients (mask recomputation)
+  const float* bn_shift;
+  const float* bn_mean;     // EPI_BNRED: [Nc] batch (or running) mean
   int N, Hi, Wi, Ci;
   int Hg, Wg;          // GEMM row grid per image: m = (n*Hg + gy)*Wg + gx
   int Ho, Wo, Nc;      // output tensor dims (Nc = GEMM N)
@@ -102,6 +114,21 @@ struct WgradParams {
   int gx;              // (co tile, ci tile, tap) blocks per split; the launch is 1-D: gx * splitK blocks
   int xcd;             // 1: XCD-aware block order — all blocks of one split (same dY / X rows) run on ONE XCD and share its L2
 };
+
+// EPI_BNRED request of a dgrad (engine.hip conv_dgrad_launch_br): the result is the dz of a BatchNorm whose input is Y (same
+// shape as dX); partial rows -> `partial`, count -> rows_out
+struct BnRedArgs {
+  const float* Y;
+  const unsigned* bits;      // 1-bit ReLU mask of the BatchNorm(+residual) output, or null: recompute from Y, scale, shift
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  float* partial;
+  int rows_out;              // partial rows written (all launches of the dgrad)
+};
+int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
+                         int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, BnRedArgs* br,
+                         hipStream_t s);
 
 // ---- launchers (conv.hip) ----
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
@@ -151,7 +178,8 @@ int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbit
                          const float* shift, const float* mean, const float* invstd, float* partials, long long rows, int C,
                          int dt, hipStream_t s);
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
-                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s);
+                                float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s,
+                                const float* second_sum_scale = nullptr /* EPI_BNRED partials: sum(g (y - mean)) * invstd[c] */);
 int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits, const void* Y, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2, void* dY,
                         long long rows, int C, int dt, hipStream_t s);

@@ -710,6 +710,8 @@ static int gg_use_glds() {
     case EPI_RELU: LAUNCH(EPI_RELU); break;                                         \
     case EPI_BIAS | EPI_RELU: LAUNCH(EPI_BIAS | EPI_RELU); break;                   \
     case EPI_MASK_OUT: LAUNCH(EPI_MASK_OUT); break;                                 \
+    case EPI_BNRED: LAUNCH(EPI_BNRED); break;                                       \
+    case EPI_BNRED | EPI_MASKED_ADD: LAUNCH(EPI_BNRED | EPI_MASKED_ADD); break;     \
     default:                                                                        \
       set_last_error("gather_gemm: unsupported epilogue flag combination %d", p.flags); \
       return 1;                                                                     \
@@ -724,6 +726,7 @@ double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem) {
   if (p.flags & EPI_ACCUM) b += elem * out;
   if (p.flags & EPI_MASKED_ADD) b += elem * out + out / 8.0;
   if (p.flags & EPI_MASK_OUT) b += elem * out;
+  if (p.flags & EPI_BNRED) b += elem * out + (p.bn_bits ? out / 8.0 : 0.0) + 8.0 * bnred_partial_rows(p.M) * p.Nc;   // + y, mask, partials
   return b;
 }
 

@@ -406,6 +406,8 @@ static int halo_launch(const GatherGemmParams& p, hipStream_t s) {
     case EPI_STATS: return halo_launch_one<BM, BN, WM, WN, EPI_STATS>(p, s);
     case EPI_ACCUM: return halo_launch_one<BM, BN, WM, WN, EPI_ACCUM>(p, s);
     case EPI_MASKED_ADD: return halo_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD>(p, s);
+    case EPI_BNRED: return halo_launch_one<BM, BN, WM, WN, EPI_BNRED>(p, s);
+    case EPI_BNRED | EPI_MASKED_ADD: return halo_launch_one<BM, BN, WM, WN, EPI_BNRED | EPI_MASKED_ADD>(p, s);
     default: set_last_error("conv3x3_halo(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }
@@ -464,6 +466,8 @@ static int gg16_launch(const GatherGemmParams& p, int grid, hipStream_t s) {
     case EPI_STATS: return gg16_launch_one<BM, BN, WM, WN, EPI_STATS, NST, BK>(p, grid, s);
     case EPI_ACCUM: return gg16_launch_one<BM, BN, WM, WN, EPI_ACCUM, NST, BK>(p, grid, s);
     case EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD, NST, BK>(p, grid, s);
+    case EPI_BNRED: return gg16_launch_one<BM, BN, WM, WN, EPI_BNRED, NST, BK>(p, grid, s);
+    case EPI_BNRED | EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_BNRED | EPI_MASKED_ADD, NST, BK>(p, grid, s);
     default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }

@@ -125,6 +125,71 @@ __device__ __forceinline__ void gg_stats(const GatherGemmParams& p, f32x16 (&acc
   }
 }
 
+// ---- EPI_BNRED: BatchNorm-backward partials accumulated in the store phase of a dgrad epilogue -----------------------------
+// In the store phase a lane holds V consecutive columns of one result row per store instruction and walks 64 rows of its wave in
+// steps of RPI = 64 / LPR rows (LPR = lanes per row). Sums live in 2 V registers; after the 64 rows the lanes that share a column
+// vector (lane, lane ^ LPR, lane ^ 2 LPR, ...) are combined with shuffles and lanes < LPR write the partial row. Every (64-row
+// group, column range) belongs to exactly one wave: no atomics, no block barrier, fixed summation order.
+template <int V>
+struct BnRedAcc {
+  float s1[V], s2[V];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  }
+};
+
+// coefficient vectors of the lane's V columns (loop-invariant)
+template <int V>
+struct BnRedCoef {
+  float sc[V], sh[V], mu[V];
+  __device__ __forceinline__ void load(const GatherGemmParams& p, int gcol) {
+    const bool ok = gcol < p.Nc;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      mu[e] = ok ? p.bn_mean[gcol + e] : 0.f;
+      sc[e] = (ok && !p.bn_bits) ? p.bn_scale[gcol + e] : 0.f;
+      sh[e] = (ok && !p.bn_bits) ? p.bn_shift[gcol + e] : 0.f;
+    }
+  }
+};
+
+// dz: the V values just stored at element offset eo (already rounded to the storage type), y: the BatchNorm input there
+template <int V>
+__device__ __forceinline__ void bnred_add(BnRedAcc<V>& a, const BnRedCoef<V>& k, const GatherGemmParams& p, const float (&dz)[V],
+                                          const float (&y)[V], long long eo) {
+  unsigned bits = ~0u;
+  if (p.bn_bits) bits = p.bn_bits[eo >> 5] >> (int)(eo & 31);     // eo is a multiple of V (4 or 8): the V bits sit in one word
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const bool on = p.bn_bits ? ((bits >> e) & 1u) != 0u : fmaf(y[e], k.sc[e], k.sh[e]) > 0.f;
+    const float g = on ? dz[e] : 0.f;
+    a.s1[e] += g;
+    a.s2[e] = fmaf(g, y[e] - k.mu[e], a.s2[e]);
+  }
+}
+
+template <int V, int LPR>
+__device__ __forceinline__ void bnred_flush(BnRedAcc<V>& a, const GatherGemmParams& p, int lane, long long prow, int gcol, bool group_valid) {
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      a.s1[e] += __shfl_xor(a.s1[e], o);
+      a.s2[e] += __shfl_xor(a.s2[e], o);
+    }
+  if (lane < LPR && gcol < p.Nc && group_valid) {
+    float* d1 = p.stats + (prow * 2 + 0) * p.Nc + gcol;
+    float* d2 = p.stats + (prow * 2 + 1) * p.Nc + gcol;
+#pragma unroll
+    for (int e = 0; e < V; e += 4) {
+      *reinterpret_cast<f32x4*>(d1 + e) = f32x4{a.s1[e], a.s1[e + 1], a.s1[e + 2], a.s1[e + 3]};
+      *reinterpret_cast<f32x4*>(d2 + e) = f32x4{a.s2[e], a.s2[e + 1], a.s2[e + 2], a.s2[e + 3]};
+    }
+  }
+  a.clear();
+}
+
 // ---- shared epilogue: BatchNorm partials from the accumulators + LDS-transposed, 16-byte-per-lane output stores ----
 // Each wave transposes its 32 x (TN*32) accumulator slabs through a private LDS slab so that every store instruction
 // writes whole 128/256-byte row segments (dwordx4 per lane) instead of single dwords; no block barrier is involved, so the
@@ -156,6 +221,13 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
   const int gcol = n0 + wn * CW + ecol;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if ((EPI & EPI_BIAS) && gcol < p.Nc) bias4 = ldg4(p.bias + gcol);
+  BnRedAcc<4> bnacc;
+  BnRedCoef<4> bncoef;
+  if constexpr ((EPI & EPI_BNRED) != 0) {
+    static_assert(TM % 2 == 0, "EPI_BNRED: a wave covers whole 64-row groups");
+    bnacc.clear();
+    bncoef.load(p, gcol);
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -206,9 +278,23 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
           for (int e = 0; e < 4; ++e) v[e] = (z[e] > 0.f) ? v[e] : 0.f;
         }
         st4_out(dst, v);
+        if constexpr ((EPI & EPI_BNRED) != 0) {
+          f32x4 vr = v;                                                    // as stored: rounded once for bf16 tensors
+          if constexpr (sizeof(OT) == 2) vr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+          const f32x4 yv = ld4t(reinterpret_cast<const OT*>(p.bn_y) + roff + gcol);
+          const float dz[4] = {vr[0], vr[1], vr[2], vr[3]};
+          const float yy[4] = {yv[0], yv[1], yv[2], yv[3]};
+          bnred_add<4>(bnacc, bncoef, p, dz, yy, roff + gcol);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();   // the slab is private to the wave: its own LDS accesses execute in order
+    if constexpr ((EPI & EPI_BNRED) != 0) {
+      if (tm & 1) {                                                        // two 32-row tiles = one 64-row group
+        const int g0 = m0 + (wm * TM + tm - 1) * 32;
+        bnred_flush<4, F4>(bnacc, p, lane, (long long)(g0 >> 6), gcol, g0 < p.M);
+      }
+    }
   }
 }
 
@@ -238,6 +324,19 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
   const int erow = lane / F8;
   const int gcol = n0 + wn * CW + ecol;
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+  BnRedAcc<8> bnacc;
+  BnRedCoef<8> bncoef;
+  if constexpr ((EPI & EPI_BNRED) != 0) {
+    bnacc.clear();
+    bncoef.load(p, gcol);
+  }
+  auto bnred8 = [&](const bf16x8 dzv, long long eo) __attribute__((always_inline)) {
+    const bf16x8 yv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bn_y) + eo);
+    float dz[8], yy[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dz[e] = (float)dzv[e]; yy[e] = (float)yv[e]; }
+    bnred_add<8>(bnacc, bncoef, p, dz, yy, eo);
+  };
   auto row_off = [&](int row) -> long long {
     if (out_simple) return (long long)row * p.Nc;
     const int n = row / hwg;
@@ -267,8 +366,17 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
       for (int it = 0; it < TMP * 32 / RPI; ++it) {
         const int lr = it * RPI + erow;
         const int row = m0 + (wm * TM + ps * TMP) * 32 + lr;
-        if (row < p.M && gcol < p.Nc)
-          st8_out(outp + row_off(row) + gcol, *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol));
+        if (row < p.M && gcol < p.Nc) {
+          const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
+          const long long eo = row_off(row) + gcol;
+          st8_out(outp + eo, ov);
+          if constexpr ((EPI & EPI_BNRED) != 0) bnred8(ov, eo);
+        }
+      }
+      if constexpr ((EPI & EPI_BNRED) != 0) {
+        static_assert(TMP == 2, "EPI_BNRED: one 64-row group per pass");
+        const int g0 = m0 + (wm * TM + ps * TMP) * 32;
+        bnred_flush<8, F8>(bnacc, p, lane, (long long)(g0 >> 6), gcol, g0 < p.M);
       }
     }
   } else {
@@ -315,10 +423,18 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
           st8_out(outp + eo, o);
+          if constexpr ((EPI & EPI_BNRED) != 0) bnred8(o, eo);
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if constexpr ((EPI & EPI_BNRED) != 0) {
+        if (tm & 1) {                                                      // two 32-row tiles = one 64-row group
+          const int g0 = m0 + (wm * TM + tm - 1) * 32;
+          bnred_flush<8, F8>(bnacc, p, lane, (long long)(g0 >> 6), gcol, g0 < p.M);
+        }
+      }
     }
+    static_assert(!(EPI & EPI_BNRED) || TM % 2 == 0, "EPI_BNRED: waves cover whole 64-row groups");
   }
 }
 

@@ -73,6 +73,9 @@ struct Plan {
   bool wg_pending[2] = {false, false};
   int a_next = 0;         // which of A0/A1 the next dY goes to
   int roles[5] = {0, 1, 2, 3, 4};
+  int fuse_bnred = 1;       // BatchNorm-backward partials from the producing dgrad's epilogue (EPI_BNRED); 0: stand-alone reduce pass
+  int dout_fused_rows = 0;  // > 0: the dgrad that wrote the running output gradient also wrote the BatchNorm-backward partials of the
+                            // block that consumes it next (EPI_BNRED): that many partial rows wait in the partial buffer
   int use_side = -1;
 };
 
@@ -175,6 +178,8 @@ Plan* plan_create(int size, int F, int dtype) {
     if (pr > partial_max) partial_max = pr;
     pr = (long long)(i == 0 ? bn_bwd_pool_partial_rows(M, c.Co, dtype) : bn_bwd_partial_rows(M, c.Co, dtype)) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
+    pr = ((long long)bnred_partial_rows(M) + 4) * 2 * c.Co;     // EPI_BNRED: one row per 64 result rows (+ one per stride-2 parity class)
+    if (pr > partial_max) partial_max = pr;
     const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
     if (welems > wmax) wmax = welems;
     if (i == 0) {
@@ -251,11 +256,22 @@ int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, 
 // dX[N,Hi,Wi,Ci] = dgrad of conv(k, stride, pad) given dY[N,Ho,Wo,Co] and Wt[Ci][k*k][Co]
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
                       int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s) {
+  return conv_dgrad_launch_br(dY, Wt, dX, add0, add1, addbits, N, Hi, Wi, Ci, Co, k, stride, pad, flags, dt, nullptr, s);
+}
+int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1,
+                         const unsigned* addbits, int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags,
+                         int dt, BnRedArgs* br, hipStream_t s) {
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   R3M_REQUIRE(stride == 1 || stride == 2, "dgrad: stride %d", stride);
   GatherGemmParams g;
   memset(&g, 0, sizeof g);
   g.dtype = dt;
+  if (br) {
+    flags |= EPI_BNRED;
+    g.bn_y = br->Y; g.bn_bits = br->bits; g.bn_scale = br->scale; g.bn_shift = br->shift; g.bn_mean = br->mean;
+    g.stats = br->partial;
+    br->rows_out = 0;
+  }
   g.A = dY; g.B = Wt; g.out = dX; g.add0 = add0; g.add1 = add1; g.addbits = addbits;
   g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co;   // the GEMM "input" is dY
   g.Ho = Hi; g.Wo = Wi; g.Nc = Ci;
@@ -270,6 +286,7 @@ int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* 
       }
     g.ntaps = t;
     g.simple_rows = (k == 1 && pad == 0) ? 1 : 0;
+    if (br) br->rows_out = bnred_partial_rows(g.M);
     return launch_gather_gemm(g, s);
   }
   // stride 2: one launch per output parity class; class (py,px) only sees taps with (py+pad-kh), (px+pad-kw) even
@@ -291,7 +308,12 @@ int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* 
       }
       c.ntaps = t;
       c.simple_rows = 0;
+      R3M_REQUIRE(!(br && t == 0), "dgrad: EPI_BNRED on a parity class without taps (1x1 stride-2) is not supported");
       if (t == 0 && (flags & EPI_ACCUM) && !(flags & EPI_MASKED_ADD)) continue;  // nothing to add
+      if (br) {                                          // every parity class appends its own partial rows
+        c.stats = br->partial + (long long)br->rows_out * 2 * c.Nc;
+        br->rows_out += bnred_partial_rows(c.M);
+      }
       if (int e = launch_gather_gemm(c, s)) return e;
     }
   return 0;
@@ -443,17 +465,22 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
 }
 
 // BatchNorm(+ReLU / residual mask) backward of layer L: dZ -> dY, parameter gradients into the flat gradient buffer
-static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY) {
+// fused_rows > 0: the dgrad that produced dZ already wrote this BatchNorm's backward partials (EPI_BNRED, sum(g) and
+// sum(g (y - mean)) per 64 rows) into the partial buffer: the stand-alone first pass is skipped
+static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY, int fused_rows = 0) {
   Plan& P = c.P;
   const long long rows = (long long)P.F * L.Ho * L.Wo;
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   const float* Y = c.arena + L.Y_off;
-  TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.dt, c.s));
-  const int prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
+  int prow = fused_rows;
+  if (!fused_rows) {
+    TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.dt, c.s));
+    prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
+  }
   TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
   TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
-                                  coef(c, L, 5), c.accumulate, L.Co, c.s));
+                                  coef(c, L, 5), c.accumulate, L.Co, c.s, fused_rows ? coef(c, L, 1) : nullptr));
   TRY(launch_bn_bwd_apply(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
                           dY, rows, L.Co, c.dt, c.s));
   return 0;
@@ -464,11 +491,23 @@ static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
                            c.accumulate, c.dt, c.s);
 }
 
-static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const unsigned* addbits) {
+// bn_of: the conv layer whose BatchNorm consumes dX as its dz (its Y has dX's shape), bn_bits: that BatchNorm's output mask bits
+// (block outputs) or null (mask recomputed from Y). *fused_rows_out receives the partial-row count (0 = not fused).
+static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const unsigned* addbits,
+                 const ConvSpec* bn_of = nullptr, const unsigned* bn_bits = nullptr, int* fused_rows_out = nullptr) {
   float* Wt = c.arena + c.P.wt_off;
   if (c.dt == DT_BF16) TRY(launch_transpose_w_bf16(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
   else TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
-  return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.dt, c.s);
+  if (fused_rows_out) *fused_rows_out = 0;
+  // 1x1 stride-2 dgrads leave three of four parity classes without taps (plain zero / no-op launches): not fused
+  const bool fuse = bn_of && fused_rows_out && c.P.fuse_bnred && !(L.stride == 2 && L.k == 1);
+  if (!fuse)
+    return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.dt, c.s);
+  BnRedArgs br{c.arena + bn_of->Y_off, bn_bits, c.arena + bn_of->coef_off + 2LL * bn_of->Co, c.arena + bn_of->coef_off + 3LL * bn_of->Co,
+               c.arena + bn_of->coef_off, c.arena + c.P.partial_off, 0};
+  TRY(conv_dgrad_launch_br(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.dt, &br, c.s));
+  *fused_rows_out = br.rows_out;
+  return 0;
 }
 
 // Backward stages: 0 = avgpool + layer4, 1 = layer3, 2 = layer2, 3 = layer1 + stem. The gradient w.r.t. the current
@@ -490,6 +529,7 @@ static int side_init(Plan& P) {
     // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
     // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
     P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0) != 0;
+    P.fuse_bnred = R3M_ENV_INT("R3M_BNRED", 1) != 0;      // probe builds: 0 = stand-alone BatchNorm-backward reduce passes (A/B)
   }
   if (!P.use_side || P.side) return 0;
   if (hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking) != hipSuccess) { set_last_error("side stream: create failed"); return 1; }
@@ -559,6 +599,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       for (int r = 0; r < 5; ++r) role[r] = r;
       P.a_next = 0;
       P.wg_pending[0] = P.wg_pending[1] = false;
+      P.dout_fused_rows = 0;     // the last block's output gradient comes from the pool: its BatchNorm runs the stand-alone reduce
       TRY(launch_avgpool_bwd(dh, Gp(0), F, last.Ho * last.Wo, last.Co, dt, s));
     }
     for (int bi = (int)P.blocks.size() - 1; bi >= 0; --bi) {
@@ -572,22 +613,29 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       // last conv of the block: its BatchNorm output joined the residual add, mask comes from the block output
       const float* dz = dOut;
       const unsigned* zmask = Out;
+      // partials of the BatchNorm that consumes dz, written by the dgrad that produced dz (EPI_BNRED) — 0: none
+      int dz_fused = P.dout_fused_rows;
+      P.dout_fused_rows = 0;
+      // the block whose output gradient this block's last dgrad completes, and the BatchNorm (its last conv's) that will read it
+      const BlockSpec* Bprev = bi > 0 ? &P.blocks[bi - 1] : nullptr;
+      const ConvSpec* Lprev_last = Bprev ? &P.convs[Bprev->conv[Bprev->nconv - 1]] : nullptr;
+      const unsigned* prev_bits = Bprev ? reinterpret_cast<const unsigned*>(arena + Bprev->mask_off) : nullptr;
       int ai;
       for (int j = B.nconv - 1; j >= 1; --j) {
         const ConvSpec& L = P.convs[B.conv[j]];
         const ConvSpec& Lprev = P.convs[B.conv[j - 1]];
         float* dY = next_A(&ai);
         TRY(acquire_A(ai));
-        TRY(bn_backward(c, L, dz, zmask, dY));          // HBM-bound: overlaps the previous layer's wgrad
+        TRY(bn_backward(c, L, dz, zmask, dY, dz_fused));     // HBM-bound: overlaps the previous layer's wgrad
         TRY(wait_wgrads());
-        TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr));
+        TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr, &Lprev, nullptr, &dz_fused));   // Gb = dz of Lprev's BatchNorm + its partials
         TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
         dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward before a later dgrad rewrites it
       }
       const ConvSpec& L1 = P.convs[B.conv[0]];
       float* dY1 = next_A(&ai);
       TRY(acquire_A(ai));
-      TRY(bn_backward(c, L1, dz, zmask, dY1));
+      TRY(bn_backward(c, L1, dz, zmask, dY1, dz_fused));
       TRY(wait_wgrads());
       if (B.ds >= 0) {
         const ConvSpec& Ld = P.convs[B.ds];
@@ -596,12 +644,14 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         int ad;
         float* dYd = next_A(&ad);
         TRY(acquire_A(ad));
-        TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1)
+        TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1); always the stand-alone reduce (second consumer of dOut)
         TRY(wait_wgrads());
         TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
         TRY(wgrad_async(Ld, Xin, dYd, ad));
       } else {
-        TRY(dgrad(c, L1, dY1, Gc, EPI_MASKED_ADD, dOut, Out));
+        // Gc = dgrad + masked residual gradient = the previous block's COMPLETE output gradient: also emit the partials of the
+        // BatchNorm that will consume it (the previous block's last one, masked by that block's output bits)
+        TRY(dgrad(c, L1, dY1, Gc, EPI_MASKED_ADD, dOut, Out, Lprev_last, prev_bits, &P.dout_fused_rows));
         TRY(wgrad_async(L1, Xin, dY1, ai));
       }
       // C becomes the gradient of the previous block's output; the old D is free (only the main stream ever read it)

@@ -413,3 +413,93 @@ def test_adam_matches_committed_golden(hip, golden_dir):
         np.testing.assert_allclose(p.cpu().numpy(), g[f"p_{i}"], rtol=1e-6, atol=2e-7)
     np.testing.assert_allclose(m.cpu().numpy(), g["exp_avg"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(v.cpu().numpy(), g["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+
+
+def _pack_bits(mask_nhwc):
+    """[..] bool (NHWC element order) -> uint32 words, bit i of word w = element 32 w + i (the engine's 1-bit ReLU mask layout)."""
+    flat = mask_nhwc.reshape(-1).to(torch.int64)
+    pad = (-flat.numel()) % 32
+    if pad:
+        flat = torch.cat([flat, torch.zeros(pad, dtype=torch.int64)])
+    words = (flat.view(-1, 32) << torch.arange(32, dtype=torch.int64)).sum(1)
+    return (words & 0xFFFFFFFF).to(torch.int64).numpy().astype(np.uint32)
+
+
+BNRED_CASES = [(2, 56, 64, 256, 1, 1, 0), (2, 56, 256, 64, 1, 1, 0), (2, 28, 128, 128, 3, 1, 1), (2, 56, 128, 128, 3, 2, 1),
+               (3, 14, 256, 256, 3, 1, 1), (5, 7, 2048, 512, 1, 1, 0), (2, 56, 64, 128, 3, 2, 1), (3, 9, 64, 64, 3, 1, 1),
+               (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["recompute", "bits", "bits+residual"])
+@pytest.mark.parametrize("case", BNRED_CASES, ids=_ids)
+def test_dgrad_epilogue_emits_bn_backward_partials(hip, case, mode, dtype):
+    """EPI_BNRED (round 2): the dgrad epilogue also accumulates the consumer BatchNorm's backward partials — per 64 result rows
+    sum(g) and sum(g (y - mean)), g = dz * [ReLU mask] — so the stand-alone reduce pass (one more read of dz and y) disappears
+    from the engine. Checked against float64 on the STORED dz (one rounding for bf16) for the three forms the engine uses:
+    mask recomputed from y (inner BatchNorms), mask bits (block outputs), mask bits + masked residual-gradient join; stride 1 and
+    2 (four parity launches appending their partial rows), partial tiles, Ci = 32..2048."""
+    N, H, Ci, Co, k, s, p = case
+    if dtype == "bf16" and (Ci % 64 or Co % 64):
+        pytest.skip("bf16 kernels: channel counts are multiples of 64")
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    dt = 0 if dtype == "fp32" else 1
+    q = (lambda t: t) if dtype == "fp32" else (lambda t: t.to(torch.bfloat16).float())
+    Ho = (H + 2 * p - k) // s + 1
+    w = q(rnd((Co, Ci, k, k), 2, -0.2, 0.2))
+    dy = q(rnd((N, Co, Ho, Ho), 3))
+    y = q(rnd((N, Ci, H, H), 4, -1.0, 1.5))                                  # the consumer BatchNorm's input
+    res = q(rnd((N, Ci, H, H), 5))                                           # residual gradient joining at this tensor
+    res_mask = rnd((N, Ci, H, H), 6) > 0.0
+    scale = rnd((Ci,), 7, 0.5, 1.5)
+    shift = rnd((Ci,), 8, -0.5, 0.5)
+    mean = rnd((Ci,), 9, -0.2, 0.4)
+    bn_mask_bits = rnd((N, Ci, H, H), 10) > -0.3
+    # recomputed mask = fmaf(y, scale, shift) > 0 in fp32: keep every element away from the kink so the decision is unambiguous
+    for _ in range(4):
+        v = y.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        y = q(torch.where(v.abs() < 1e-3, y + 0.05, y))
+    assert not bool(((y.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).abs() < 1e-5).any())
+    # float64 expectation
+    xr = torch.zeros((N, Ci, H, H), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w.double(), stride=s, padding=p).backward(dy.double())
+    dz = xr.grad
+    if mode == "bits+residual":
+        dz = dz + res.double() * res_mask
+    dz_stored = dz.float() if dtype == "fp32" else dz.to(torch.bfloat16).float()
+    on = bn_mask_bits if mode != "recompute" else (y.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) > 0
+    g = dz_stored.double() * on
+    exp_s1 = g.sum((0, 2, 3)).numpy()
+    exp_s2 = (g * (y.double() - mean.double().view(1, -1, 1, 1))).sum((0, 2, 3)).numpy()
+    # device
+    dyd, yd = nhwc(dy).to(DEV).to(tdt), nhwc(y).to(DEV).to(tdt)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)                           # fp32 master (dgrad converts for bf16)
+    dxd = torch.full((N, H, H, Ci), float("nan"), device=DEV, dtype=tdt)
+    wsb = hip.r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    rows = hip.r3m_conv2d_dgrad_bnred_rows(N, H, H, s)
+    part = torch.full((rows, 2, Ci), float("nan"), device=DEV)
+    resd = nhwc(res).to(DEV).to(tdt) if mode == "bits+residual" else None
+    resb = torch.from_numpy(_pack_bits(nhwc(res_mask)).astype(np.int64)).to(torch.int32).to(DEV) if mode == "bits+residual" else None
+    bnb = None if mode == "recompute" else torch.from_numpy(_pack_bits(nhwc(bn_mask_bits)).astype(np.int64)).to(torch.int32).to(DEV)
+    sc, sh, mu = scale.to(DEV), shift.to(DEV), mean.to(DEV)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    rc = hip.r3m_conv2d_dgrad_bnred_dt(dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p,
+                                       ptr(resd), ptr(resb), yd.data_ptr(), ptr(bnb), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                                       part.data_ptr(), dt, st())
+    assert rc == 0, hip.r3m_last_error()
+    dx = nchw(dxd.float().cpu())
+    tol = 2e-5 if dtype == "fp32" else 2.0 ** -8
+    assert rel_err(dx.numpy(), dz.numpy())[0] < tol
+    assert torch.isfinite(part).all(), "a partial row was not written"
+    # the partials must describe the dz the kernel STORED (bf16: its own rounding of its own fp32 sum)
+    g_dev = dx.double() * on
+    got_s1 = part[:, 0].double().sum(0).cpu().numpy()
+    got_s2 = part[:, 1].double().sum(0).cpu().numpy()
+    ref_s1 = g_dev.sum((0, 2, 3)).numpy()
+    ref_s2 = (g_dev * (y.double() - mean.double().view(1, -1, 1, 1))).sum((0, 2, 3)).numpy()
+    scale1 = float(np.abs(g_dev).sum((0, 2, 3)).max())
+    np.testing.assert_allclose(got_s1, ref_s1, rtol=0, atol=2e-6 * scale1)
+    np.testing.assert_allclose(got_s2, ref_s2, rtol=0, atol=4e-6 * scale1)
+    # and agree with the float64 expectation to the accuracy of the stored tensor
+    np.testing.assert_allclose(got_s1, exp_s1, rtol=0, atol=(2e-5 if dtype == "fp32" else 2e-2) * scale1 / np.sqrt(N * H * H) + 1e-6 * scale1)
