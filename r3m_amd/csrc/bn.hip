@@ -11,6 +11,14 @@
 #include "conv_dev.h"
 #include <cstdlib>
 
+// Traversal order of the streaming BatchNorm passes. The 256 MiB Infinity Cache still holds the TAIL of the tensor the previous
+// kernel streamed; a consumer that walks the rows in the opposite direction hits it first. R3M_BN_REV bit 1: forward apply, bit 2:
+// backward reduce, bit 4: backward apply walk from the last block down (compile-time; variants built by tools/experiments/build_probes.sh).
+#ifndef R3M_BN_REV
+#define R3M_BN_REV 0
+#endif
+#define BN_BID(bit) ((R3M_BN_REV & (bit)) ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x)
+
 namespace r3m {
 
 // activations are float or bf16_t (T); per-channel coefficients, statistics and partial sums are always fp32
@@ -198,9 +206,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ Y
   // A block owns `span` consecutive items and walks them 256 at a time; the launcher only picks span > 256 when 256 is a
   // multiple of C/4, so the thread's channels and their coefficients are loop-invariant (loaded once, and the block's
   // accesses stay one contiguous range). n4 is a multiple of 8 when maskbits is used: an 8-lane nibble group is all in or out.
-  long long i = (long long)blockIdx.x * span + threadIdx.x;
+  long long i = (long long)BN_BID(1) * span + threadIdx.x;
   if (i >= n4) return;
-  const long long end = min((long long)(blockIdx.x + 1) * span, n4);
+  const long long end = min((long long)(BN_BID(1) + 1) * span, n4);
   const int c = ((int)(i & c4mask)) * 4;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
   f32x4 sc2 = sc, sh2 = sh;
@@ -270,9 +278,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd16_kernel(const bf16_t* __restr
   // A block owns `span` consecutive items, 256 at a time: 256 is a multiple of C/8, so a thread keeps ITS 8 channels and loads
   // the per-channel coefficients once — at 16 B of payload per load the coefficient vectors would otherwise be most of the
   // L1 traffic. n8 is a multiple of 4 when maskbits is used: a 4-lane word group is all in or all out.
-  long long i = (long long)blockIdx.x * span + threadIdx.x;
+  long long i = (long long)BN_BID(1) * span + threadIdx.x;
   if (i >= n8) return;
-  const long long end = min((long long)(blockIdx.x + 1) * span, n8);
+  const long long end = min((long long)(BN_BID(1) + 1) * span, n8);
   const int c = ((int)(i & c8mask)) * 8;
   const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c);
   f32x8 sc2, sh2;
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const int tcol = threadIdx.x % cpb4, trow = threadIdx.x / cpb4;
   const int rpp = 256 / cpb4;
   const int c = (blockIdx.y * cpb4 + tcol) * 4;
-  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  const long long r_begin = (long long)BN_BID(2) * rows_per_block;
   long long r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
@@ -410,8 +418,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s1 += red[0][k * cpb4 + tcol];
       s2 += red[1][k * cpb4 + tcol];
     }
-    st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c, s1);
-    st4(partials + ((long long)blockIdx.x * 2 + 1) * C + c, s2);
+    st4(partials + ((long long)BN_BID(2) * 2 + 0) * C + c, s1);
+    st4(partials + ((long long)BN_BID(2) * 2 + 1) * C + c, s2);
   }
 }
 
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce16_kernel(const bf16_t* __re
   const int tcol = threadIdx.x % cpb8, trow = threadIdx.x / cpb8;
   const int rpp = 256 / cpb8;
   const int c = (blockIdx.y * cpb8 + tcol) * 8;
-  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  const long long r_begin = (long long)BN_BID(2) * rows_per_block;
   long long r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c), mu = ld8f(mean + c), is = ld8f(invstd + c);
@@ -454,8 +462,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce16_kernel(const bf16_t* __re
       s1.lo += red[0][k * cpb8 + tcol]; s1.hi += red[1][k * cpb8 + tcol];
       s2.lo += red[2][k * cpb8 + tcol]; s2.hi += red[3][k * cpb8 + tcol];
     }
-    float* p1 = partials + ((long long)blockIdx.x * 2 + 0) * C + c;
-    float* p2 = partials + ((long long)blockIdx.x * 2 + 1) * C + c;
+    float* p1 = partials + ((long long)BN_BID(2) * 2 + 0) * C + c;
+    float* p2 = partials + ((long long)BN_BID(2) * 2 + 1) * C + c;
     st4(p1, s1.lo); st4(p1 + 4, s1.hi);
     st4(p2, s2.lo); st4(p2 + 4, s2.hi);
   }
@@ -538,9 +546,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                             const float* __restrict__ invstd, const float* __restrict__ c1,
                                                             const float* __restrict__ c2, T* __restrict__ dY,
                                                             long long n4, int c4mask, int span) {
-  long long i = (long long)blockIdx.x * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd_kernel
+  long long i = (long long)BN_BID(4) * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd_kernel
   if (i >= n4) return;
-  const long long end = min((long long)(blockIdx.x + 1) * span, n4);
+  const long long end = min((long long)(BN_BID(4) + 1) * span, n4);
   const int c = ((int)(i & c4mask)) * 4;
   const f32x4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
   const f32x4 k1 = ld4(c1 + c), k2 = ld4(c2 + c);
@@ -576,9 +584,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const bf16_t* __res
                                                               const float* __restrict__ invstd, const float* __restrict__ c1,
                                                               const float* __restrict__ c2, bf16_t* __restrict__ dY, long long n8,
                                                               int c8mask, int span) {
-  long long i = (long long)blockIdx.x * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd16_kernel
+  long long i = (long long)BN_BID(4) * span + threadIdx.x;   // span consecutive items per block, see bn_act_fwd16_kernel
   if (i >= n8) return;
-  const long long end = min((long long)(blockIdx.x + 1) * span, n8);
+  const long long end = min((long long)(BN_BID(4) + 1) * span, n8);
   const int c = ((int)(i & c8mask)) * 8;
   const f32x8 sc = ld8f(scale + c), sh = ld8f(shift + c), mu = ld8f(mean + c), is = ld8f(invstd + c);
   const f32x8 k1 = ld8f(c1 + c), k2 = ld8f(c2 + c);

@@ -529,7 +529,14 @@ static int side_init(Plan& P) {
     // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
     // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
     P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0) != 0;
-    P.fuse_bnred = R3M_ENV_INT("R3M_BNRED", 1) != 0;      // probe builds: 0 = stand-alone BatchNorm-backward reduce passes (A/B)
+    // fp32 plans only: there the dgrad is MFMA-bound and the extra epilogue loads ride under other blocks' matrix work (A/B on one
+    // box, probe build: 343.0 / 341.7 ms -> 338.5 / 339.0 ms per ResNet-50 step). bf16 plans are HBM/epilogue-bound already and
+    // measured SLOWER with it (ResNet-50 94.0 -> 96.1 ms, ResNet-34 94.7 -> 102.1 ms), so they keep the stand-alone reduce.
+    // R3M_BNRED (probe builds): 0 = off everywhere, 2 = on for bf16 too.
+    {
+      const int v = R3M_ENV_INT("R3M_BNRED", 1);
+      P.fuse_bnred = v == 2 || (v == 1 && P.dtype == DT_F32);
+    }
   }
   if (!P.use_side || P.side) return 0;
   if (hipStreamCreateWithFlags(&P.side, hipStreamNonBlocking) != hipSuccess) { set_last_error("side stream: create failed"); return 1; }
