@@ -28,7 +28,7 @@ MB_PER_FRAME_BF16 = {50: 289.8, 34: 97.1, 18: 64.5}          # algorithmic HBM b
 PEAK_HBM_GBS = 8000.0                                        # HBM3E spec (≈6300 GB/s achievable), MI355X_MICROARCH.md
 PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0                               # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), not the 2:1-sparse figure
-KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
+KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad; 32- and 16-wide-K kernels, all epilogues incl. the BatchNorm-backward partials)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
           "wgrad_64x64"]
 
 
