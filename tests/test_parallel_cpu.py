@@ -49,6 +49,36 @@ def _worker(rank, world, port, q):
         # param.grad views see the reduced values
         w = dict(m.convnet.named_parameters())["layer4.1.conv2.weight"]
         assert w.grad is not None and w.grad.data_ptr() >= g.data_ptr()
+        # language head: its gradients go out FIRST (at the first stage hook), once per step, and finish() re-arms the step
+        torch.manual_seed(200 + rank)
+        m2 = R3M("cpu", 1e-4, 64, size=18, langweight=1.0, tcnweight=1.0)
+        net2 = make_network_wrapper(m2)
+        head = m2.lang_rew
+        hg = head.flat_grads()
+        for step in range(2):
+            hg.fill_(float(rank + 1 + step))
+            head._has_grads = True
+            g2 = m2.convnet.flat_grads()
+            g2.fill_(float(10 * (rank + 1)))
+            before = net2.sync.launched
+            for stage in range(4):
+                off, cnt = m2.convnet.stage_range(stage)
+                m2.convnet._stage_hook(stage, off, cnt)
+                if stage == 0:
+                    assert net2.sync.launched == before + 2          # head buffer + the layer4 slice
+            assert net2.sync.launched == before + 5
+            net2.finish_gradient_sync()
+            assert net2.sync.launched == before + 5                  # nothing left for finish() to issue
+            assert torch.allclose(hg, torch.full_like(hg, (sum(range(1, world + 1)) / world) + step))
+            assert torch.allclose(g2, torch.full_like(g2, 10 * sum(range(1, world + 1)) / world))
+        # a step without encoder backward (no stage hook fired): finish() still reduces the head
+        hg.fill_(float(rank))
+        head._has_grads = True
+        before = net2.sync.launched
+        net2.finish_gradient_sync()
+        assert net2.sync.launched == before + 1 and torch.allclose(hg, torch.full_like(hg, (world - 1) / 2.0))
+        # one-rank semantics of `force` are exercised on the GPU (tests/test_gpu_ddp.py); here: world 2 is active without it
+        assert net2.sync.active
         # plain GradSync on an arbitrary buffer + no-op at count 0
         s = GradSync()
         buf = torch.full((10,), float(rank))
