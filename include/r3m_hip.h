@@ -64,6 +64,10 @@ int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, floa
 int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi,
                             int Wi, const float* params, float* buffers, void* arena, float* h_out, int training,
                             r3m_stream_t stream);
+/* Per-plan switch of the backward schedule: 1 = the first pass of BatchNorm backward is computed inside the epilogue of the dgrad
+ * that produces its dz (EPI_BNRED; default for fp32 plans), 0 = stand-alone reduce passes (default for bf16 plans, where the
+ * fused form measured slower). Both schedules compute the same sums (different summation order). Returns the previous value. */
+int r3m_resnet_set_fused_bn_reduce(r3m_resnet_t h, int on);
 int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
                         int stage_end, int accumulate, r3m_stream_t stream);
 

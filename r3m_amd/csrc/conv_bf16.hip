@@ -424,7 +424,9 @@ static bool halo_eligible(const GatherGemmParams& p) {
   if (p.ntaps != 9 || p.simple_rows || p.is != 1 || p.os != 1 || p.ooy != 0 || p.oox != 0) return false;
   if (p.Hg != p.Hi || p.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || (p.Ci & 63) || (p.Nc & 7)) return false;
   if (!(p.Nc % 128 == 0 || p.Nc == 64)) return false;
-  if (p.flags != 0 && p.flags != EPI_STATS && p.flags != EPI_ACCUM && p.flags != EPI_MASKED_ADD) return false;
+  if (p.flags != 0 && p.flags != EPI_STATS && p.flags != EPI_ACCUM && p.flags != EPI_MASKED_ADD && p.flags != EPI_BNRED &&
+      p.flags != (EPI_BNRED | EPI_MASKED_ADD))
+    return false;
   for (int k = 0; k < 9; ++k)
     if (p.dy[k] < -1 || p.dy[k] > 1 || p.dx[k] < -1 || p.dx[k] > 1) return false;
   return true;

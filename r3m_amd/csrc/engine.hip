@@ -73,6 +73,7 @@ struct Plan {
   bool wg_pending[2] = {false, false};
   int a_next = 0;         // which of A0/A1 the next dY goes to
   int roles[5] = {0, 1, 2, 3, 4};
+  bool bnred_init = false;
   int fuse_bnred = 1;       // BatchNorm-backward partials from the producing dgrad's epilogue (EPI_BNRED); 0: stand-alone reduce pass
   int dout_fused_rows = 0;  // > 0: the dgrad that wrote the running output gradient also wrote the BatchNorm-backward partials of the
                             // block that consumes it next (EPI_BNRED): that many partial rows wait in the partial buffer
@@ -116,6 +117,7 @@ Plan* plan_create(int size, int F, int dtype) {
   Plan* Pp = new Plan();
   Plan& P = *Pp;
   P.size = size; P.F = F; P.dtype = dtype;
+  P.fuse_bnred = dtype == DT_F32 ? 1 : 0;   // see side_init(): measured gain for fp32 plans, measured loss for bf16 plans
   const bool bottleneck = (size == 50);
   const int expansion = bottleneck ? 4 : 1;
   const int nblk[4] = {size == 18 ? 2 : 3, size == 18 ? 2 : 4, size == 18 ? 2 : 6, size == 18 ? 2 : 3};
@@ -529,13 +531,16 @@ static int side_init(Plan& P) {
     // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
     // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
     P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0) != 0;
+  }
+  if (!P.bnred_init) {
+    P.bnred_init = true;
     // fp32 plans only: there the dgrad is MFMA-bound and the extra epilogue loads ride under other blocks' matrix work (A/B on one
     // box, probe build: 343.0 / 341.7 ms -> 338.5 / 339.0 ms per ResNet-50 step). bf16 plans are HBM/epilogue-bound already and
-    // measured SLOWER with it (ResNet-50 94.0 -> 96.1 ms, ResNet-34 94.7 -> 102.1 ms), so they keep the stand-alone reduce.
+    // measured slightly SLOWER with it (ResNet-50 95.6 -> 96.2 ms, ResNet-34 97.0 -> 97.9 ms), so they keep the stand-alone reduce.
     // R3M_BNRED (probe builds): 0 = off everywhere, 2 = on for bf16 too.
     {
       const int v = R3M_ENV_INT("R3M_BNRED", 1);
-      P.fuse_bnred = v == 2 || (v == 1 && P.dtype == DT_F32);
+      if (v != 1) P.fuse_bnred = v == 2;       // probe builds: 0 = off everywhere, 2 = on for bf16 too; 1 = the plan's own setting
     }
   }
   if (!P.use_side || P.side) return 0;
@@ -727,5 +732,7 @@ void plan_destroy(Plan* P) {
   delete P;
 }
 int* plan_gd(Plan* P) { return &P->gd; }
+// per-plan option: 1 = BatchNorm-backward partials from the dgrad epilogues (EPI_BNRED), 0 = stand-alone reduce passes
+int plan_set_fuse_bnred(Plan* P, int on) { const int old = P->fuse_bnred; P->fuse_bnred = on ? 1 : 0; return old; }
 
 }  // namespace r3m
