@@ -236,27 +236,48 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
       for (int r = 0; r < 16; ++r)
         slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
     __builtin_amdgcn_wave_barrier();   // the slab is private to the wave: its own LDS accesses execute in order
+    auto roff_of = [&](int row) -> long long {
+      if (out_simple) return (long long)row * p.Nc;
+      const int n = row / hwg;
+      const int rem = row - n * hwg;
+      const int gy = rem / p.Wg;
+      const int gx = rem - gy * p.Wg;
+      return (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
+    };
+    // Read-modify-write epilogues: the operands of the next YPRE rows (y of EPI_BNRED, the residual gradient of EPI_MASKED_ADD,
+    // the old result of EPI_ACCUM) are requested BEFORE those rows' stores are issued — the compiler cannot move a load above an
+    // earlier store through un-restricted pointers, so without this every row would pay a full load latency.
+    constexpr int NIT = 32 / RPI;
+    constexpr int YPRE = NIT < 4 ? NIT : 4;
+    constexpr bool PRELOAD = (EPI & (EPI_BNRED | EPI_MASKED_ADD | EPI_ACCUM)) != 0;
+    f32x4 ypre[YPRE], gpre[YPRE], opre[YPRE];
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      if constexpr (PRELOAD) {
+        if (it % YPRE == 0) {
+#pragma unroll
+          for (int q = 0; q < YPRE; ++q) {
+            const int rowq = m0 + (wm * TM + tm) * 32 + (it + q) * RPI + erow;
+            ypre[q] = gpre[q] = opre[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (it + q < NIT && rowq < p.M && gcol < p.Nc) {
+              const long long eq = roff_of(rowq) + gcol;
+              if constexpr ((EPI & EPI_BNRED) != 0) ypre[q] = ld4t(reinterpret_cast<const OT*>(p.bn_y) + eq);
+              if constexpr ((EPI & EPI_MASKED_ADD) != 0) gpre[q] = ld4t(reinterpret_cast<const OT*>(p.add0) + eq);
+              if constexpr ((EPI & EPI_ACCUM) != 0) opre[q] = ld4t(reinterpret_cast<const OT*>(p.out) + eq);
+            }
+          }
+        }
+      }
       const int lr = it * RPI + erow;
       const int row = m0 + (wm * TM + tm) * 32 + lr;
       if (row < p.M && gcol < p.Nc) {
-        long long roff;
-        if (out_simple) {
-          roff = (long long)row * p.Nc;
-        } else {
-          const int n = row / hwg;
-          const int rem = row - n * hwg;
-          const int gy = rem / p.Wg;
-          const int gx = rem - gy * p.Wg;
-          roff = (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
-        }
+        const long long roff = roff_of(row);
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
         OT* dst = reinterpret_cast<OT*>(p.out) + roff + gcol;     // activation pointers are typed float in the params struct;
         if (EPI & EPI_BIAS) v += bias4;                           // with OT = bf16_t they address bf16 tensors
-        if (EPI & EPI_ACCUM) v += ld4t(dst);
+        if (EPI & EPI_ACCUM) v += opre[it % YPRE];
         if (EPI & EPI_MASKED_ADD) {
-          const f32x4 g = ld4t(reinterpret_cast<const OT*>(p.add0) + roff + gcol);
+          const f32x4 g = gpre[it % YPRE];
           if (p.addbits) {
             const long long i4 = (roff + gcol) >> 2;
             const unsigned nb = (p.addbits[i4 >> 3] >> (4 * (int)(i4 & 7))) & 15u;
@@ -281,7 +302,7 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
         if constexpr ((EPI & EPI_BNRED) != 0) {
           f32x4 vr = v;                                                    // as stored: rounded once for bf16 tensors
           if constexpr (sizeof(OT) == 2) vr = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
-          const f32x4 yv = ld4t(reinterpret_cast<const OT*>(p.bn_y) + roff + gcol);
+          const f32x4 yv = ypre[it % YPRE];
           const float dz[4] = {vr[0], vr[1], vr[2], vr[3]};
           const float yy[4] = {yv[0], yv[1], yv[2], yv[3]};
           bnred_add<4>(bnacc, bncoef, p, dz, yy, roff + gcol);
@@ -391,8 +412,20 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
         for (int r = 0; r < 16; ++r)
           slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + tn * 32 + lrow] = acc[tm][tn][r];
       __builtin_amdgcn_wave_barrier();
+      // operands of the tile's rows requested before any of its stores (see gg_epilogue: loads cannot move above earlier stores)
+      constexpr int NIT = 32 / RPI;
+      bf16x8 opre[NIT], gpre[NIT];
 #pragma unroll
-      for (int it = 0; it < 32 / RPI; ++it) {
+      for (int q = 0; q < NIT; ++q) {
+        const int rowq = m0 + (wm * TM + tm) * 32 + q * RPI + erow;
+        if (rowq < p.M && gcol < p.Nc) {
+          const long long eq = row_off(rowq) + gcol;
+          if constexpr ((EPI & EPI_ACCUM) != 0) opre[q] = *reinterpret_cast<const bf16x8*>(outp + eq);
+          if constexpr ((EPI & EPI_MASKED_ADD) != 0) gpre[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eq);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
         const int lr = it * RPI + erow;
         const int row = m0 + (wm * TM + tm) * 32 + lr;
         if (row < p.M && gcol < p.Nc) {
@@ -403,12 +436,12 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
           if (EPI & EPI_ACCUM) {
-            const bf16x8 o = *reinterpret_cast<const bf16x8*>(outp + eo);
+            const bf16x8 o = opre[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
           }
           if (EPI & EPI_MASKED_ADD) {
-            const bf16x8 g = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eo);
+            const bf16x8 g = gpre[it];
             if (p.addbits) {
               const unsigned nb = (p.addbits[eo >> 5] >> (int)(eo & 31)) & 255u;
 #pragma unroll
