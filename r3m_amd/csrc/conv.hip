@@ -1418,7 +1418,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-constexpr int STEM_WG_BLOCKS = 768;
+// persistent blocks: the kernel holds 130 VGPRs + 48 AGPRs -> TWO blocks per CU; 768 blocks (round 1) ran as one and a half rounds
+// of resident blocks with equal work each, i.e. the last third of the time at half occupancy
+#ifndef R3M_STEM_WG_BLOCKS
+#define R3M_STEM_WG_BLOCKS 512
+#endif
+constexpr int STEM_WG_BLOCKS = R3M_STEM_WG_BLOCKS;
 size_t stem_wgrad_ws_floats() { return (size_t)STEM_WG_BLOCKS * 64 * 160; }
 
 // dw147[co][kh*21 + j] (+)= dw160[co][kh*22 + j]
