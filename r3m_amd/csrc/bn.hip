@@ -97,17 +97,31 @@ __global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const float* __res
   }
 }
 
-static inline int reduce_slices(int rows) {
+// Slices of the partial-row reduce: enough blocks for narrow layers with MANY rows (64 channels at 56 x 56 x 1280 frames: 62 720
+// EPI_BNRED rows, one column block — 64 slices left 192 CUs idle and a 245-row serial walk per thread), within the accumulator
+// buffer of 64 x 2 x 2048 doubles (S * C <= 131072).
+static inline int reduce_slices(int rows, int C) {
   int s = (rows + 15) / 16;
-  if (s > 64) s = 64;
+  int cap = 131072 / (C > 0 ? C : 1);
+  if (cap > 256) cap = 256;
+  if (cap < 64) cap = 64;
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
   return s;
 }
 
-// acc must hold 64*2*C doubles; the slice count is a pure function of the partial-row count (reduce_slices), so
+// bytes of the fp64 slice accumulator for C channels (the largest slice count reduce_slices can pick for that C)
+size_t bn_acc_bytes(int C) {
+  int cap = 131072 / (C > 0 ? C : 1);
+  if (cap > 256) cap = 256;
+  if (cap < 64) cap = 64;
+  return (size_t)cap * 2 * C * 8;
+}
+
+// acc must hold 131072 * 2 doubles (64 slices x 2 x 2048 channels, or more slices of fewer channels); the slice count is a pure function of the partial-row count (reduce_slices), so
 // the finalize launchers below take the same `stat_rows` and recompute it.
 int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc, hipStream_t s) {
-  const int S = reduce_slices(rows);
+  const int S = reduce_slices(rows, C);
   hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(ceil_div(C, 64), S), dim3(256), 0, s, partials, rows, C, acc);
   return check_launch("bn_stats_reduce");
 }
@@ -166,7 +180,7 @@ int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, c
                             float* invstd, float* scale, float* shift, int C, hipStream_t s) {
   const double inv_count = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows), inv_count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows, C), inv_count,
                      unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
   return check_launch("bn_finalize");
 }
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
                                 float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s,
                                 const float* second_sum_scale) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows, C),
                      1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C, second_sum_scale);
   return check_launch("bn_bwd_finalize");
 }

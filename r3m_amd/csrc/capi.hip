@@ -383,12 +383,12 @@ static size_t bn_acc_off(long long rows, int C) {
   size_t p = (size_t)bn_bwd_partial_rows(rows, C, DT_F32) * 2 * C * 4;   // the fp32 geometry has the most rows
   return (p + 255) / 256 * 256;
 }
-static size_t bn_c12_off(long long rows, int C) { return bn_acc_off(rows, C) + (size_t)64 * 2 * C * 8; }
+static size_t bn_c12_off(long long rows, int C) { return bn_acc_off(rows, C) + bn_acc_bytes(C); }
 size_t r3m_bn_workspace_bytes(long long rows, int C) { return bn_c12_off(rows, C) + (size_t)2 * C * 4; }
 
 int r3m_bn_train_coeffs(const float* stats, int stats_rows, long long count, const float* gamma, const float* beta, float* rm,
                         float* rv, float momentum, float eps, float* coef, void* ws, size_t ws_bytes, int C, r3m_stream_t stream) {
-  R3M_REQUIRE(ws_bytes >= (size_t)64 * 2 * C * 8, "bn_train_coeffs: workspace too small");
+  R3M_REQUIRE(ws_bytes >= bn_acc_bytes(C), "bn_train_coeffs: workspace too small (need %zu)", bn_acc_bytes(C));
   double* acc = static_cast<double*>(ws);
   if (int e = launch_bn_stats_reduce(stats, stats_rows, C, acc, S(stream))) return e;
   return launch_bn_finalize_rows(acc, stats_rows, count, gamma, beta, rm, rv, momentum, eps, coef, coef + C, coef + 2 * C,

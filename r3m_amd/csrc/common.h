@@ -164,7 +164,8 @@ size_t stem_wgrad16_ws_floats();
 int launch_stem_wgrad16(const void* xn16, const void* dY, float* dw147, float* ws, int F, int accumulate, hipStream_t s);
 
 // ---- launchers (bn.hip) ----
-int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /*[<=64][2][C]*/, hipStream_t s);
+size_t bn_acc_bytes(int C);   // fp64 slice accumulator: [slices <= max(64, min(256, 131072 / C))][2][C]
+int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /* bn_acc_bytes(C) */, hipStream_t s);
 int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
                             float* invstd, float* scale, float* shift, int C, hipStream_t s);
