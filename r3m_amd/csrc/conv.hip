@@ -763,7 +763,9 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     // short main loop + wide output: single tap, K <= 256, N >= 2 K (expanding / downsample 1x1 convolutions) -> 16-wide K tiles
-    const bool short_loop = p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci && (p.Ci & 31) == 0 && R3M_ENV_INT("R3M_GG_K16", 1) != 0;
+    // R3M_GG_K16 (probe builds): 0 = never, 1 = the rule above, 2 = every wide launch (experiment: 4 blocks per CU everywhere)
+    const int k16_mode = R3M_ENV_INT("R3M_GG_K16", 1);
+    const bool short_loop = (p.Ci & 31) == 0 && (k16_mode == 2 || (k16_mode == 1 && p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci));
     if (short_loop) {
 #define LAUNCH_K16(E) hipLaunchKernelGGL((gather_gemm_k16_kernel<E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_K16)

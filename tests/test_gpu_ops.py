@@ -498,7 +498,7 @@ def test_dgrad_epilogue_emits_bn_backward_partials(hip, case, mode, dtype):
     got_s2 = part[:, 1].double().sum(0).cpu().numpy()
     ref_s1 = g_dev.sum((0, 2, 3)).numpy()
     ref_s2 = (g_dev * (y.double() - mean.double().view(1, -1, 1, 1))).sum((0, 2, 3)).numpy()
-    scale1 = float(np.abs(g_dev).sum((0, 2, 3)).max())
+    scale1 = float(g_dev.abs().sum((0, 2, 3)).max())
     np.testing.assert_allclose(got_s1, ref_s1, rtol=0, atol=2e-6 * scale1)
     np.testing.assert_allclose(got_s2, ref_s2, rtol=0, atol=4e-6 * scale1)
     # and agree with the float64 expectation to the accuracy of the stored tensor
