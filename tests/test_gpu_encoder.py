@@ -223,7 +223,7 @@ def test_small_ragged_batches_vs_oracle(hip, B):
     assert torch.isfinite(sd["conv1.weight"]).all() and int(sd["bn1.num_batches_tracked"]) == 1
 
 
-@pytest.mark.parametrize("size,F,precision", [(18, 8, "fp32"), (34, 5, "fp32"), (50, 3, "fp32"), (50, 4, "bf16"), (34, 8, "bf16")])
+@pytest.mark.parametrize("size,F,precision", [(18, 8, "fp32"), (18, 1, "fp32"), (34, 5, "fp32"), (50, 3, "fp32"), (50, 4, "bf16"), (34, 8, "bf16")])
 def test_fused_and_standalone_bn_backward_reduce_agree(hip, size, F, precision):
     """Round 2: for fp32 plans the first pass of BatchNorm backward runs inside the dgrad epilogues (EPI_BNRED). The two backward
     schedules (r3m_resnet_set_fused_bn_reduce 1 / 0) must give the same parameter gradients — same sums, different summation
