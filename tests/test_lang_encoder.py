@@ -22,14 +22,14 @@ def test_features_match_the_reference_lang_encoder(golden_dir):
     enc = _encoder()
     f_all = enc(tiny_text.SENTENCES)
     assert f_all.shape == (8, 768) and not f_all.requires_grad
-    assert rel_err(f_all.numpy(), g["feats_all"])[0] < 1e-6
+    assert rel_err(f_all.numpy(), g["feats_all"])[0] < 1e-5
     # the padding quirk (models_language.py:34): mean(1) runs over padded positions, so the SAME sentence gets a
     # different feature in a batch with a longer neighbour — reproduced, not "fixed"
     f_short = enc([tiny_text.SENTENCES[0], tiny_text.SENTENCES[3]])
-    assert rel_err(f_short.numpy(), g["feats_short"])[0] < 1e-6
+    assert rel_err(f_short.numpy(), g["feats_short"])[0] < 1e-5
     assert float((f_short[0] - f_all[0]).abs().max()) > 0.1
     # numpy array of strings, as a DataLoader collates them (`langs.tolist()`, models_language.py:24-27)
-    assert rel_err(enc(np.array(tiny_text.SENTENCES[3:6])).numpy(), g["feats_array_input"])[0] < 1e-6
+    assert rel_err(enc(np.array(tiny_text.SENTENCES[3:6])).numpy(), g["feats_array_input"])[0] < 1e-5
     # tensors are frozen precomputed features and pass through untouched (BASELINE configs[2])
     t = torch.randn(3, 768)
     assert enc(t) is t
