@@ -72,7 +72,7 @@ def cpu_baseline(size, clips, seconds_budget=25.0):
                       f"{clips} clips = {clips*5} frames, best of {len(times)} after 1 warm-up, {n_thr} threads on {cpu_model}"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)      # >= 20 timed steps after >= 5 warm-ups
@@ -99,46 +99,109 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
-    args = ap.parse_args()
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="re-launch under torch.distributed.run also for --gpus 1 (the self-spawn path on a one-GPU box; N > 1 always does)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short measurements of the other BASELINE configs that the default (headline) run appends under "
+                         "'secondary' AFTER the headline's timed region")
+    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--secondary-warmup", type=int, default=5)
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU (WORLD_SIZE={world}); launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the
-    # gradient all-reduces are issued — also with one rank, where a mean over one rank is the identity: `torchrun
-    # --nproc-per-node 1 bench.py --gpus 1` therefore executes the same collective / barrier / max-over-ranks code that N = 8 runs.
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
+def is_headline(args):
+    """The default workload = BASELINE configs[1]; only that run appends the 'secondary' measurements."""
+    return (args.size == 50 and args.precision == "fp32" and args.langweight == 0 and args.doaug == "none"
+            and args.encoder_only_frames == 0 and args.clips_per_gpu == 256)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(args, environ, argv, port=None):
+    """How `python bench.py --gpus N` becomes N ranks. Returns None when this process IS a rank (N == 1, or launched by
+    torch.distributed.run: RANK/WORLD_SIZE in the environment), else the command line that re-runs this script under
+    `python -m torch.distributed.run`, one rank per GPU over RCCL — the reference scales inside one process with
+    nn.DataParallel (/root/reference/r3m/train_representation.py:27-31), so its users never type a launcher either.
+    Pure function of its arguments (tests/test_bench_launch.py)."""
+    if "RANK" in environ or "WORLD_SIZE" in environ:
+        world = int(environ.get("WORLD_SIZE", "1"))
+        if args.gpus != world:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                             f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+        return None
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus == 1 and not args.force_launcher:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_spawn(cmd, n):
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    import subprocess
+    return subprocess.call(cmd, env=env)
+
+
+def workload_label(w, world):
+    """Which BASELINE config a workload IS (never a label for work that is not executed)."""
+    bf16 = w["precision"] == "bf16"
+    if w["encoder_only_frames"] > 0:
+        return "encoder-only continuity point"
+    if bf16:
+        lab = ("BASELINE configs[4]" if w["size"] == 34 and w["doaug"] == "rctraj" else
+               "BASELINE configs[2]" if w["size"] == 50 and w["langweight"] > 0 else
+               f"bf16 variant of the ResNet-{w['size']} step")
+    elif w["size"] == 50 and w["langweight"] > 0:
+        lab = "BASELINE configs[3] (full R3M loss: LP + TCN + language InfoNCE through the reward head)"
+    elif w["size"] == 50:
+        lab = "BASELINE configs[1]"
+    else:
+        lab = f"fp32 ResNet-{w['size']} variant of BASELINE configs[1]"
+    if world > 1:
+        lab += f", replicated on {world} GPUs (weak scaling, RCCL gradient mean overlapped with backward)"
+    return lab
+
+
+def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_csv=""):
+    """One workload `w` (dict: size, clips, precision, langweight, doaug, unfused_crop, encoder_only_frames): build the model,
+    W warm-up steps, then EXACTLY K timed steps between barrier + synchronize; returns the JSON object (rank 0) or None."""
+    import gc
     from r3m_amd import R3M, _lib
     from r3m_amd.parallel import make_network_wrapper
     from r3m_amd.trainer import Trainer
     L = _lib.lib()
+    rank, world, dev, use_dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["use_dist"]
+    size, B, precision = w["size"], w["clips"], w["precision"]
 
     torch.manual_seed(1)                               # config_rep.yaml seed
-    B = args.clips_per_gpu
-    model = R3M("cuda", 1e-4, 1024, size=args.size, l2weight=1e-5, l1weight=1e-5, langweight=args.langweight, tcnweight=1.0,
-                l2dist=True, bs=B, precision=args.precision)
+    model = R3M("cuda", 1e-4, 1024, size=size, l2weight=1e-5, l1weight=1e-5, langweight=w["langweight"], tcnweight=1.0,
+                l2dist=True, bs=B, precision=precision)
     model = model.to(dev)
     net = make_network_wrapper(model, force=use_dist)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    if args.doaug == "none":
+    if w["doaug"] == "none":
         frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
         get_frames = lambda: frames
     else:
         from r3m_amd import augment
         raw = torch.randint(0, 256, (B, 5, 3, 256, 256), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
         box_gen = torch.Generator().manual_seed(99 + rank)
-        get_frames = lambda: augment.random_resized_crop(raw, per_clip=(args.doaug == "rctraj"), generator=box_gen,
-                                                         fused=not args.unfused_crop)
+        get_frames = lambda: augment.random_resized_crop(raw, per_clip=(w["doaug"] == "rctraj"), generator=box_gen,
+                                                         fused=not w["unfused_crop"])
     langs = [""] * B
-    if args.langweight > 0:   # frozen DistilBERT stand-in: [B,768] N(0,1)*0.3, all clips have language
+    if w["langweight"] > 0:   # frozen DistilBERT stand-in: [B,768] N(0,1)*0.3 (SURVEY.md §8(d)), all clips have language
         gl = torch.Generator(device=dev).manual_seed(4321 + rank)
         langs = torch.randn((B, 768), generator=gl, device=dev) * 0.3
     trainer = Trainer(eval_freq=10 ** 9)
@@ -148,9 +211,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    enc_only = args.encoder_only_frames > 0
+    enc_only = w["encoder_only_frames"] > 0
     if enc_only:
-        Fe = args.encoder_only_frames
+        Fe = w["encoder_only_frames"]
         xe = torch.randint(0, 256, (Fe, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
 
         class _EncTrainer:
@@ -171,10 +234,10 @@ def main():
         get_frames = lambda: xe
 
     prewarm_steps = 0
-    if args.prewarm_seconds > 0:                        # device warm-up (clock ramp), outside both the W warm-up and the timed K steps
+    if prewarm_seconds > 0:                             # device warm-up (clock ramp), outside both the W warm-up and the timed K steps
         t_pw = time.perf_counter()
         while True:
-            go = time.perf_counter() - t_pw < args.prewarm_seconds
+            go = time.perf_counter() - t_pw < prewarm_seconds
             if use_dist:                                # every rank must run the same number of steps (collectives inside)
                 flag = torch.tensor([1 if go else 0], device=dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -184,91 +247,84 @@ def main():
             trainer.update(net, (get_frames(), langs), 0)
             torch.cuda.synchronize()
             prewarm_steps += 1
-    for i in range(args.warmup):
+    for i in range(warmup):
         trainer.update(net, (get_frames(), langs), i)
-    total_steps = prewarm_steps + args.warmup + args.steps
-    L.r3m_profile_enable(0 if args.no_kernel_timing else 1)
-    if args.launch_csv and rank == 0:
-        _lib.check(L.r3m_profile_dump_to(args.launch_csv.encode()), "profile_dump_to")
+    total_steps = prewarm_steps + warmup + steps
+    sync = getattr(net, "sync", None)
+    if sync is not None:
+        sync.time_waits(True)                           # HIP events on the compute stream around the waits for RCCL
+    L.r3m_profile_enable(1 if kernel_timing else 0)
+    if launch_csv and rank == 0:
+        _lib.check(L.r3m_profile_dump_to(launch_csv.encode()), "profile_dump_to")
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        metrics, _ = trainer.update(net, (get_frames(), langs), args.warmup + i)
+    for i in range(steps):
+        metrics, _ = trainer.update(net, (get_frames(), langs), warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     ms, launches, flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
     _lib.check(L.r3m_profile_collect(ms, launches, flops), "profile_collect")
     L.r3m_profile_enable(0)
     L.r3m_profile_dump_to(None)
+    comm_exposed_ms = sync.exposed_ms() / steps if sync is not None else None
+    if sync is not None:
+        sync.time_waits(False)
+    dt_min = dt_max = dt
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, -dt, comm_exposed_ms or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_max, dt_min, comm_exposed_ms = float(t[0].item()), -float(t[1].item()), float(t[2].item())
+        dt = dt_max
+    collectives = (f"rccl all_reduce(AVG), {net.sync.launched / max(1, total_steps):.1f} per step"
+                   + (" (one-rank group: identity, issued to exercise the path)" if world == 1 else "")) if use_dist \
+        else "none (single process)"
 
+    out = None
     if rank == 0:
-        F_total = (args.encoder_only_frames if enc_only else 5 * B) * world
+        F_total = (w["encoder_only_frames"] if enc_only else 5 * B) * world
         bytes_k = (C.c_double * 4)()
         _lib.check(L.r3m_profile_collect_bytes(bytes_k), "profile_collect_bytes")
-        fps = F_total * args.steps / dt
+        fps = F_total * steps / dt
         kernels = []
         for k in range(4):
             if launches[k]:
-                kernels.append({"kernel": KCLASS[k], "launches_per_step": launches[k] / args.steps,
-                                "avg_launch_ms": ms[k] / launches[k], "ms_per_step": ms[k] / args.steps,
+                kernels.append({"kernel": KCLASS[k], "launches_per_step": launches[k] / steps,
+                                "avg_launch_ms": ms[k] / launches[k], "ms_per_step": ms[k] / steps,
                                 "tflops": flops[k] / (ms[k] * 1e-3) / 1e12,
                                 "algorithmic_GBps": bytes_k[k] / (ms[k] * 1e-3) / 1e9})
         dom = max(range(4), key=lambda k: ms[k])
         ach = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-        bf16 = args.precision == "bf16"
+        bf16 = precision == "bf16"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        # HBM bytes per launch of the dominant class come from the PMC passes (rocprofv3 --pmc cannot run inside this
-        # process): NOT measured in this run — read from the committed summary of the last counter run, and labelled as such.
-        traffic, traffic_source = None, None
-        pmc_name = "pmc_latest_bf16.json" if bf16 else "pmc_latest.json"
-        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.exists(pmc_path):
-            try:
-                pj = json.load(open(pmc_path))
-                traffic = pj.get("dominant_kernel_hbm_bytes_per_launch")
-                traffic_source = (f"profiles/{pmc_name} <- {pj.get('source')} (separate rocprofv3 --pmc passes of an earlier run of "
-                                  f"this command; FETCH_SIZE x2 + WRITE_SIZE, KiB units; not measured live)")
-            except Exception:
-                traffic = None
-        # which BASELINE config this run IS (never a label for work that is not executed)
-        if bf16:
-            cfg_label = ("BASELINE configs[4]" if args.size == 34 and args.doaug == "rctraj" else
-                         "BASELINE configs[2]" if args.size == 50 and args.langweight > 0 else
-                         f"bf16 variant of the ResNet-{args.size} step")
-        elif args.size == 50 and args.langweight > 0:
-            cfg_label = "BASELINE configs[3] (full R3M loss: LP + TCN + language InfoNCE through the reward head)"
-        elif args.size == 50:
-            cfg_label = "BASELINE configs[1]"
-        else:
-            cfg_label = f"fp32 ResNet-{args.size} variant of BASELINE configs[1]"
-        if world > 1:
-            cfg_label += f", replicated on {world} GPUs (weak scaling, RCCL gradient mean overlapped with backward)"
+        alg_bytes_per_launch = bytes_k[dom] / max(1, launches[dom])
+        traffic, traffic_source = pmc_traffic(bf16, size, B, KCLASS[dom])
+        cfg_label = workload_label(w, world)
         out = {
-            "metric": "encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU" if args.size == 50 and B == 256 else
-                      f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2 bs={B}/GPU",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "encoder frames/sec (fwd+bwd) ResNet-50 224^2 bs=256/GPU" if size == 50 and B == 256 else
+                      f"encoder frames/sec (fwd+bwd) ResNet-{size} 224^2 bs={B}/GPU",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "prewarm_steps": prewarm_steps,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg_label}: ResNet-{args.size} R3M step (encoder fwd + LP/TCN{'/language' if args.langweight > 0 else ''} loss + bwd + Adam), "
+            "config": {"workload": f"{cfg_label}: ResNet-{size} R3M step (encoder fwd + LP/TCN{'/language' if w['langweight'] > 0 else ''} loss + bwd + Adam), "
                                    f"{'bf16 activations / bf16 MFMA, fp32 master weights + statistics + Adam' if bf16 else 'fp32'}, "
-                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={args.langweight:g} l1=l2=1e-5 l2dist doaug={args.doaug}",
+                                   f"{B} clips = {5*B} frames of 224x224x3 per GPU, tcnweight=1 langweight={w['langweight']:g} l1=l2=1e-5 l2dist doaug={w['doaug']}",
                        "clips_per_gpu": B, "frames_per_gpu": 5 * B, "parallelism": f"dp{world}",
-                       "collectives": (f"rccl all_reduce(AVG), {net.sync.launched / max(1, total_steps):.1f} per step"
-                                       + (" (one-rank group: identity, issued to exercise the path)" if world == 1 else ""))
-                                      if use_dist else "none (single process)",
-                       "final_full_loss": metrics["full_loss"]},
+                       "collectives": collectives, "final_full_loss": metrics["full_loss"]},
             "roofline": {"bound": "mfma", "kernel": KCLASS[dom], "achieved": round(ach, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_ratio": round(traffic / alg_bytes_per_launch, 3) if traffic and alg_bytes_per_launch else None,
                          "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
                          "algorithmic_gflop_per_launch": round(flops[dom] / max(1, launches[dom]) / 1e9, 3),
-                         "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[args.size] / 1e3 / peak, 4),
+                         "algorithmic_mbytes_per_launch": round(alg_bytes_per_launch / 1e6, 2),
+                         "whole_step_frac": round(fps / world * GFLOP_PER_FRAME[size] / 1e3 / peak, 4),
                          "kernels": kernels},
         }
+        if use_dist:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["ms_per_step_rank_min"] = round(dt_min / steps * 1e3, 3)
+            out["ms_per_step_rank_max"] = round(dt_max / steps * 1e3, 3)
+            out["comm_exposed_ms"] = round(comm_exposed_ms, 4)     # per step, max over ranks: compute stream idle in work.wait()
         if bf16:
             # with 2-byte activations every ResNet here is under the bf16 ridge -> the bounding roof is HBM.
             # achieved = algorithmic bytes of the dominant kernel class (operands read once + results written once, summed
@@ -277,17 +333,101 @@ def main():
             mf = out["roofline"]
             out["roofline"] = {"bound": "hbm", "kernel": KCLASS[dom], "achieved": round(ach_bw, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(ach_bw / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                               "avg_launch_ms": mf["avg_launch_ms"],
-                               "algorithmic_mbytes_per_launch": round(bytes_k[dom] / max(1, launches[dom]) / 1e6, 2),
-                               "whole_step_frac": round(fps / world * MB_PER_FRAME_BF16[args.size] / 1e3 / PEAK_HBM_GBS, 4),
+                               "traffic_ratio": mf["traffic_ratio"], "avg_launch_ms": mf["avg_launch_ms"],
+                               "algorithmic_mbytes_per_launch": mf["algorithmic_mbytes_per_launch"],
+                               "whole_step_frac": round(fps / world * MB_PER_FRAME_BF16[size] / 1e3 / PEAK_HBM_GBS, 4),
                                "mfma": {"achieved": mf["achieved"], "peak": mf["peak"], "unit": "TFLOP/s", "frac": mf["frac"],
                                         "whole_step_frac": mf["whole_step_frac"]},
                                "kernels": kernels}
         if enc_only:
-            out["metric"] = f"encoder frames/sec (fwd+bwd) ResNet-{args.size} 224^2, {args.encoder_only_frames} frames/GPU, encoder only (loss = sum|h|)"
-            out["config"]["workload"] = (f"encoder-only continuity point (SURVEY.md §8(d)): ResNet-{args.size} forward + backward of sum|h| + Adam on "
-                                         f"{args.encoder_only_frames} frames of 224x224x3 per GPU, {'bf16 activations' if bf16 else 'fp32'}")
-            out["config"]["frames_per_gpu"] = args.encoder_only_frames
+            out["metric"] = f"encoder frames/sec (fwd+bwd) ResNet-{size} 224^2, {w['encoder_only_frames']} frames/GPU, encoder only (loss = sum|h|)"
+            out["config"]["workload"] = (f"encoder-only continuity point (SURVEY.md §8(d)): ResNet-{size} forward + backward of sum|h| + Adam on "
+                                         f"{w['encoder_only_frames']} frames of 224x224x3 per GPU, {'bf16 activations' if bf16 else 'fp32'}")
+            out["config"]["frames_per_gpu"] = w["encoder_only_frames"]
+    # release the activation arena (the dominant HBM allocation) before the next workload is built
+    del trainer, net, model, get_frames
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def pmc_traffic(bf16, size, clips, dom_kernel):
+    """HBM bytes per launch of the dominant class from the PMC passes (rocprofv3 --pmc cannot run inside this process): NOT
+    measured in this run — read from the committed summary of the last counter run and labelled as such. The summary is only
+    used when it describes THIS workload and THIS kernel class and its source file is still in the tree."""
+    pmc_name = "pmc_latest_bf16.json" if bf16 else "pmc_latest.json"
+    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+    if not os.path.exists(pmc_path):
+        return None, None
+    try:
+        pj = json.load(open(pmc_path))
+    except Exception as e:   # a broken summary must not take the bench line down with it
+        return None, f"profiles/{pmc_name} unreadable: {e}"
+    src = pj.get("source") or ""
+    if not os.path.exists(os.path.join(ROOT, src)):
+        return None, f"profiles/{pmc_name} names {src!r}, which is not in the tree: traffic withheld"
+    want = pj.get("workload") or {}
+    if (want.get("size"), want.get("clips")) != (size, clips):
+        return None, f"profiles/{pmc_name} was collected on ResNet-{want.get('size')} / {want.get('clips')} clips: not this workload"
+    tag = (pj.get("dominant_kernel") or "").split()[0:2]          # e.g. ["gather_gemm", "128x128"]
+    if not tag or "_".join(tag) not in dom_kernel.replace(" ", "_"):
+        return None, f"profiles/{pmc_name} describes {pj.get('dominant_kernel')!r}, the dominant class here is {dom_kernel.split(' (')[0]!r}"
+    return pj.get("dominant_kernel_hbm_bytes_per_launch"), (
+        f"profiles/{pmc_name} <- {src} (separate rocprofv3 --pmc passes of an earlier run of this command; "
+        f"FETCH_SIZE x2 + WRITE_SIZE, KiB units; not measured live)")
+
+
+SECONDARY = [   # the other single-node BASELINE configs, timed AFTER the headline so that it is unperturbed
+    ("configs[2]", dict(size=50, clips=256, precision="bf16", langweight=1.0, doaug="none")),
+    ("configs[3]", dict(size=50, clips=256, precision="fp32", langweight=1.0, doaug="none")),
+    ("configs[4]", dict(size=34, clips=512, precision="bf16", langweight=0.0, doaug="rctraj")),
+]
+
+
+def main():
+    args = parse_args()
+    cmd = launch_plan(args, os.environ, sys.argv[1:])
+    if cmd is not None:
+        raise SystemExit(self_spawn(cmd, args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the
+    # gradient all-reduces are issued — also with one rank, where a mean over one rank is the identity: `torchrun
+    # --nproc-per-node 1 bench.py --gpus 1` therefore executes the same collective / barrier / max-over-ranks code that N = 8 runs.
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist}
+
+    w = dict(size=args.size, clips=args.clips_per_gpu, precision=args.precision, langweight=args.langweight, doaug=args.doaug,
+             unfused_crop=args.unfused_crop, encoder_only_frames=args.encoder_only_frames)
+    out = measure(w, args.steps, args.warmup, args.prewarm_seconds, ctx, kernel_timing=not args.no_kernel_timing,
+                  launch_csv=args.launch_csv)
+    if is_headline(args) and not args.no_secondary and args.secondary_steps > 0:
+        sec = {}
+        for name, sw in SECONDARY:
+            sw = dict(sw, unfused_crop=False, encoder_only_frames=0)
+            try:
+                r = measure(sw, args.secondary_steps, args.secondary_warmup, min(args.prewarm_seconds, 2.0), ctx)
+            except Exception as e:   # a secondary workload must never cost the headline its line
+                if use_dist:
+                    raise            # ranks would diverge: fail loudly
+                r = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                if "error" not in r:
+                    r = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "n_gpus")} | {
+                        "workload": r["config"]["workload"], "collectives": r["config"]["collectives"],
+                        "comm_exposed_ms": r.get("comm_exposed_ms"),
+                        "roofline": {k: v for k, v in r["roofline"].items() if k != "kernels"}}
+                sec[name] = r
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_clips)
         print(json.dumps(out), flush=True)

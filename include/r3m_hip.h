@@ -54,7 +54,10 @@ int r3m_resnet_stage_range(r3m_resnet_t h, int stage, long long* offset, long lo
  * training=1: batch statistics + running-stat update (momentum 0.1, eps 1e-5); 0: running statistics. */
 int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, float* buffers, void* arena, float* h_out,
                        int training, r3m_stream_t stream);
-/* dh: [frames, out_dim]. Runs stages [stage_begin, stage_end) in order; stage 0 must come first after a forward.
+/* dh: [frames, out_dim]. Runs stages [stage_begin, stage_end) in order. The stages of one backward share state inside the plan
+ * (the running output gradient, buffer roles, BatchNorm partials written by one stage's dgrad epilogues for the next): after
+ * each forward they MUST be called in the order 0,1,2,3 (in one call or several); stage 0 may restart a backward over the same
+ * forward at any time; any other out-of-order stage, or a backward before the first forward, returns non-zero.
  * accumulate=0 overwrites grads, 1 adds to them. */
 /* The same forward fed from RAW clips through crop boxes: the rc / rctraj RandomResizedCrop(224) of the reference's loader
  * (r3m/utils/data_loaders.py:47-50,88-102) resampled INSIDE the stem pre-pass — one gather-bilinear pass from uint8 (or float

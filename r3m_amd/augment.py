@@ -142,6 +142,32 @@ class CroppedClips:
     def materialize(self):
         return crop_resize(self.raw, self.boxes, self.frames_per_box, self.out_hw).reshape(self.shape)
 
+    # Anything beyond the regrouping above needs pixels: these materialise (one stand-alone crop pass). The handle is NOT a
+    # tensor — frame order is fixed by `raw`/`boxes`, so indexing or permuting returns plain tensors, never another handle.
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device", args[0] if args and isinstance(args[0], (str, torch.device, int)) else None)
+        dtype = kwargs.get("dtype", next((a for a in args if isinstance(a, torch.dtype)), None))
+        if (dev is None or torch.device(dev) == self.device) and dtype in (None, torch.float32):
+            return self
+        return self.materialize().to(*args, **kwargs)
+
+    def cpu(self):
+        return self.materialize().cpu()
+
+    def numpy(self):
+        return self.cpu().numpy()
+
+    def __getattr__(self, name):
+        # only reached for attributes the handle does not have: fail with the contract instead of a bare AttributeError
+        if name.startswith("__"):
+            raise AttributeError(name)
+        raise TypeError(f"CroppedClips.{name}: the fused rc/rctraj batch is a handle (raw clips + crop boxes), not a tensor; it supports "
+                        f"shape / dim / reshape of the leading dims / float / contiguous / record_stream / to / cpu / indexing — call "
+                        f".materialize() for the cropped [.., 3, 224, 224] float tensor, or pass fused=False to random_resized_crop")
+
 
 def random_resized_crop(batch, per_clip=True, generator=None, fused=False):
     """batch [B,5,3,H,W] -> [B,5,3,224,224]; per_clip=True is `rctraj` (one box per clip), False is `rc`

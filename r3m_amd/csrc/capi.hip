@@ -46,13 +46,14 @@ int check_launch(const char* what) {
 
 int ensure_dyn_lds(DynLdsOptIn& cache, const void* fn, int bytes, const char* what) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { set_last_error("%s: hipGetDevice failed", what); return 1; }
-  if (bytes <= __atomic_load_n(&cache.bytes[dev], __ATOMIC_RELAXED)) return 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) { set_last_error("%s: hipGetDevice failed", what); return 1; }
+  const bool cached = dev < (int)(sizeof(cache.bytes) / sizeof(cache.bytes[0]));   // device indices beyond the cache: set it every time
+  if (cached && bytes <= __atomic_load_n(&cache.bytes[dev], __ATOMIC_RELAXED)) return 0;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
     set_last_error("%s: cannot reserve %d bytes of LDS", what, bytes);
     return 1;
   }
-  __atomic_store_n(&cache.bytes[dev], bytes, __ATOMIC_RELAXED);
+  if (cached) __atomic_store_n(&cache.bytes[dev], bytes, __ATOMIC_RELAXED);
   return 0;
 }
 

@@ -8,7 +8,7 @@
 // ---- experiment switches -------------------------------------------------------------------------------------
 // The SHIPPED library (r3m_amd/csrc/build.sh) has one code path per shape: it reads no environment variables and contains
 // none of the timing probes (some of which deliberately produce wrong results). Builds with -DR3M_PROBES
-// (tools/experiments/build_variants.sh) bring both back so the A/B measurements quoted in DESIGN.md can be repeated.
+// (tools/build_probes.sh) bring both back so the A/B measurements quoted in DESIGN.md can be repeated.
 #ifdef R3M_PROBES
 #include <cstdlib>
 #define R3M_ENV_INT(name, dflt) ([]() -> int { static const int v_ = []() { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }(); return v_; }())

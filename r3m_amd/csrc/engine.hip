@@ -78,6 +78,11 @@ struct Plan {
   int dout_fused_rows = 0;  // > 0: the dgrad that wrote the running output gradient also wrote the BatchNorm-backward partials of the
                             // block that consumes it next (EPI_BNRED): that many partial rows wait in the partial buffer
   int use_side = -1;
+  // Backward stages carry state from one r3m_resnet_backward call to the next (buffer roles, the running output gradient and — with
+  // EPI_BNRED — BatchNorm partials waiting in the shared partial buffer for the NEXT block). They are only valid in the order
+  // 0,1,2,3 after ONE forward: next_stage is what the following call must begin with (0 = a backward may (re)start, -1 = no
+  // forward has run yet).
+  int next_stage = -1;
 };
 
 static long long align64(long long x) { return (x + 63) / 64 * 64; }
@@ -401,6 +406,8 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
                      float* h_out, int training, hipStream_t s) {
   Ctx c{P, params, nullptr, bufs, arena, s, training, 0, P.dtype};
   P.last_training = training;
+  P.next_stage = 0;            // a new forward invalidates whatever an unfinished backward left behind
+  P.dout_fused_rows = 0;
   const int F = P.F;
   const int dt = P.dtype;
   if (dt == DT_BF16) TRY(launch_convert_bf16(params, arena + P.w16_off, P.n_params, s));   // bf16 image of every weight (45 MB for ResNet-50)
@@ -555,6 +562,14 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
                   int accumulate, int* gd_io, hipStream_t s) {
   Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate, P.dtype};
   const int dt = P.dtype;
+  R3M_REQUIRE(stage_begin >= 0 && stage_end <= 4 && stage_begin < stage_end, "resnet_backward: stages [%d, %d) outside [0, 4)", stage_begin, stage_end);
+  R3M_REQUIRE(P.next_stage != -1, "resnet_backward: no forward has run on this plan");
+  // stage 0 may always (re)start a backward over the saved activations (retain_graph); any other stage must continue the
+  // sequence the previous call left off at — its inputs (running output gradient, pending EPI_BNRED partials) live in the plan
+  R3M_REQUIRE(stage_begin == 0 || stage_begin == P.next_stage,
+              "resnet_backward: stage %d requested but the plan expects stage %d (stages run 0..3 in order after each forward; "
+              "stage 0 restarts)", stage_begin, P.next_stage);
+  P.next_stage = -2;           // poisoned while in flight: after a failed call only stage 0 (a restart) is accepted
   TRY(side_init(P));
   const bool side_on = P.use_side && P.side;
   Ctx cs = c;                       // context whose launches go to the side stream
@@ -694,6 +709,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
     TRY(join_side());     // a finished stage's gradients are complete on the main stream (all-reduce hook, Adam)
   }
   *gd_io = role[0];
+  P.next_stage = stage_end == 4 ? 0 : stage_end;
   return 0;
 }
 

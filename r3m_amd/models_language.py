@@ -278,7 +278,11 @@ class LanguageReward(nn.Module):
         return self._flat_g
 
     def mark_grads_stale(self):
+        """zero_grad(): the next backward overwrites the flat buffer, and until one arrives the head HAS no gradient —
+        torch.optim.Adam skips parameters whose .grad is None after zero_grad(set_to_none=True), so must the fused step
+        (and the data-parallel wrapper must not all-reduce a stale buffer)."""
         self._grad_fresh = True
+        self._has_grads = False
 
     def has_grads(self):
         return self._has_grads

@@ -71,7 +71,20 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         steps = sd.get("steps")           # round-1 snapshots carry one shared `step`
-        self._steps = [int(s) for s in steps] if steps is not None else [int(sd["step"])] * len(self.owners)
+        steps = [int(s) for s in steps] if steps is not None else [int(sd["step"])] * len(self.owners)
+        n = len(self.owners)
+        if len(steps) != n or len(sd["exp_avg"]) != n or len(sd["exp_avg_sq"]) != n:
+            # e.g. saved with langweight=0 (encoder only) and resumed with a language head, or the reverse: silently
+            # mis-assigning moments between owners would be worse than refusing
+            raise ValueError(f"FusedAdam.load_state_dict: the snapshot holds optimizer state for {len(steps)} flat buffer(s) "
+                             f"({len(sd['exp_avg'])} moment entries), this optimizer has {n} "
+                             f"({', '.join(type(o).__name__ for o in self.owners)}); was it saved with a different langweight?")
+        for i, o in enumerate(self.owners):
+            m = sd["exp_avg"][i]
+            if m is not None and m.numel() != o.flat_params().numel():
+                raise ValueError(f"FusedAdam.load_state_dict: moments of owner {i} ({type(o).__name__}) have {m.numel()} elements, "
+                                 f"its parameters {o.flat_params().numel()}")
+        self._steps = steps
         for i, o in enumerate(self.owners):
             if sd["exp_avg"][i] is not None:
                 dev = o.flat_params().device

@@ -34,6 +34,25 @@ class GradSync:
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"   # RCCL reduces with AVG natively; gloo has SUM only
         self.launched = 0               # collectives enqueued so far (tests / bench report it)
+        self._time_waits = False
+        self._wait_events = []          # (before, after) HIP events on the compute stream around finish()'s waits
+        self.on_launch = None           # test hook: callable(index, slice, work) right after a collective is enqueued
+
+    def time_waits(self, on):
+        """bench.py: bracket the waits of finish() with HIP events on the compute stream. The first event fires when the last
+        backward kernel retires, the second once every outstanding all-reduce has been joined: their distance is the time the
+        compute stream sat idle for communication (`comm_exposed_ms`); 0 when RCCL finished under the backward."""
+        self._time_waits = bool(on)
+        self._wait_events.clear()
+
+    def exposed_ms(self):
+        """Sum over the finish() calls since time_waits(True); synchronises on the recorded events."""
+        tot = 0.0
+        for a, b in self._wait_events:
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        self._wait_events.clear()
+        return tot
 
     def reduce_slice(self, flat, offset, count):
         if not self.active or count == 0:
@@ -43,12 +62,22 @@ class GradSync:
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         work = dist.all_reduce(sl, op=op, group=self.group, async_op=True)
         self._pending.append((work, sl, not self._avg))
+        if self.on_launch is not None:
+            self.on_launch(self.launched - 1, sl, work)
 
     def finish(self):
+        timed = self._time_waits and self._pending and self._pending[0][1].is_cuda
+        if timed:
+            ev_a = torch.cuda.Event(enable_timing=True)
+            ev_a.record()
         for work, sl, needs_div in self._pending:
             work.wait()           # on GPUs: the current stream waits for RCCL's stream; no host block
             if needs_div:
                 sl.div_(self.world)
+        if timed:
+            ev_b = torch.cuda.Event(enable_timing=True)
+            ev_b.record()
+            self._wait_events.append((ev_a, ev_b))
         self._pending.clear()
 
     def broadcast(self, tensor, src=0):

@@ -58,7 +58,7 @@ class Workspace:
             raise NameError('Invalid Dataset')
         mk = lambda it: iter(torch.utils.data.DataLoader(it, batch_size=cfg.batch_size, num_workers=cfg.num_workers, pin_memory=True))  # noqa: E731
         # batches are copied to HBM (and cropped, for rc/rctraj) one step ahead on a copy stream
-        self.train_loader = CudaPrefetcher(mk(train_it), self.device, self._gpu_transform(cfg.doaug))
+        self.train_loader = CudaPrefetcher(mk(train_it), self.device, self._gpu_transform(cfg.doaug, cfg.seed + 31 * self.rank))
         self.val_loader = CudaPrefetcher(mk(val_it), self.device, None)
         self.model = make_network(cfg.agent)
         self.timer = utils.Timer()
@@ -71,11 +71,14 @@ class Workspace:
         return self._global_step
 
     @staticmethod
-    def _gpu_transform(doaug):
+    def _gpu_transform(doaug, seed=0):
         if doaug in ("rc", "rctraj"):
             from .augment import random_resized_crop
-            # boxes only: the resample itself happens inside the encoder's stem pre-pass (augment.CroppedClips)
-            return lambda x: random_resized_crop(x, per_clip=(doaug == "rctraj"), fused=True)
+            # Boxes only: the resample itself happens inside the encoder's stem pre-pass (augment.CroppedClips). The boxes come from
+            # their OWN generator: in the reference they are drawn in loader workers (data_loaders.py:88-102), never from the main
+            # process's stream that Trainer.update's randperm draws consume (trainer.py:86-92,136-137).
+            gen = torch.Generator().manual_seed(0x5EED ^ int(seed))
+            return lambda x: random_resized_crop(x, per_clip=(doaug == "rctraj"), generator=gen, fused=True)
         return None
 
     def train(self):

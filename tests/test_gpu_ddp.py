@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _build(size):
+def _build(size, dev="cuda:0"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import detgen
@@ -31,7 +31,7 @@ def _build(size):
     m = R3M("cuda", 1e-4, 1024, size=size, l2weight=1.0, l1weight=0.5, langweight=0.0, tcnweight=0.0)
     shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
     m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes).items()})
-    return m.to("cuda:0")
+    return m.to(dev)
 
 
 def _lp_backward(model, frames):
@@ -196,4 +196,263 @@ def test_bench_under_torchrun_one_rank(hip):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["collectives"].startswith("rccl all_reduce(AVG), 5.0 per step")
-    assert out["roofline"]["traffic_source"] is None or "not measured live" in out["roofline"]["traffic_source"]
+    # the committed counter summary describes the ResNet-50 headline, not this ResNet-18 run: withheld, and the line says why
+    assert out["roofline"]["traffic"] is None and "not this workload" in out["roofline"]["traffic_source"]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# RCCL across devices (VERDICT r2 "next" #2). One process per GPU, backend "nccl" (= RCCL), world in {1, 2, 4, 8}: the
+# world-1 case always runs (same worker code on the one-GPU test box: a one-rank group with forced collectives), the others
+# arm themselves when that many GPUs are visible and are SKIPPED — not failed — otherwise.
+# The reference's counterpart: nn.DataParallel at /root/reference/r3m/train_representation.py:27-31, r3m/__init__.py:72.
+# ------------------------------------------------------------------------------------------------------------------------
+
+def _need_gpus(world):
+    have = torch.cuda.device_count()
+    if have < world:
+        pytest.skip(f"needs {world} GPUs, {have} visible")
+
+
+def _rccl_init(rank, world, port):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return dev
+
+
+def _run_ranks(target, world, *extra, timeout=1500):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r, v in res.items():
+        assert not (isinstance(v, str) and v.startswith("FAIL")), f"rank {r}: {v}"
+    return res
+
+
+def _guarded(fn, rank, world, port, q, *extra):
+    try:
+        q.put((rank, fn(rank, world, port, *extra)))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _equiv_rank(rank, world, port):
+    """N ranks x B/N frames, BatchNorm on running statistics, LP loss -> the averaged gradient every rank holds
+    after the staged RCCL all-reduce equals the one-process gradient on all B frames."""
+    dev = _rccl_init(rank, world, port)
+    from oracle import detgen
+    from r3m_amd.parallel import DistributedR3M, make_network_wrapper
+    m = _build(18, dev)
+    net = make_network_wrapper(m, force=True)
+    assert isinstance(net, DistributedR3M) and net.sync.active and net.sync._avg and net.sync.world == world
+    frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to(dev)
+    per = 8 // world
+    core = net.module
+    core.convnet.eval()
+    core.encoder_opt.zero_grad()
+    h = net(frames[rank * per:(rank + 1) * per])
+    # the single-process loss is a mean over all 8 frames; the rank-local mean over 8/N frames, averaged over N ranks, is that
+    loss = torch.linalg.norm(h, ord=2, dim=-1).mean() + 0.5 * torch.linalg.norm(h, ord=1, dim=-1).mean()
+    loss.backward()
+    assert net.sync.launched == 4                       # layer4, layer3, layer2, layer1+stem went out during backward
+    net.finish_gradient_sync()
+    torch.cuda.synchronize()
+    return core.convnet.flat_grads().cpu().numpy()
+
+
+def _equiv_worker(rank, world, port, q):      # module-level: mp "spawn" pickles the target by name
+    _guarded(_equiv_rank, rank, world, port, q)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rccl_ranks_reproduce_single_process_gradients(hip, world):
+    from oracle import detgen
+    from r3m_amd.parallel import SingleDevice
+    _need_gpus(world)
+    res = _run_ranks(_equiv_worker, world)
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0], res[r])      # RCCL AVG leaves the same bits on every rank
+    single = SingleDevice(_build(18))
+    frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to("cuda:0")
+    g1 = _lp_backward(single, frames).cpu().numpy()
+    err = np.abs(res[0] - g1).max() / np.abs(g1).max()
+    print(f"rccl world {world} vs single process: max-rel {err:.3e}")
+    if world == 1:
+        np.testing.assert_array_equal(res[0], g1)          # mean over one rank is the identity, bit for bit
+    assert err < 2e-4                                      # per-rank partial sums group the fp32 reductions differently
+
+
+def _steps_rank(rank, world, port):
+    """Three full Trainer.update steps (train-mode BatchNorm, LP + TCN + language loss through the reward head, Adam) on
+    DIFFERENT clips per rank: parameters of the encoder and of the head must stay bit-identical across ranks."""
+    dev = _rccl_init(rank, world, port)
+    from oracle import detgen
+    from r3m_amd import R3M
+    from r3m_amd.parallel import make_network_wrapper
+    from r3m_amd.trainer import Trainer
+    torch.manual_seed(100 + rank)                          # ranks start from DIFFERENT weights: the constructor's broadcast must fix that
+    m = R3M("cuda", 1e-3, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=1.0, tcnweight=1.0).to(dev)
+    net = make_network_wrapper(m, force=True)
+    B = 4
+    frames = torch.from_numpy(detgen.frames(f"ddp3-{rank}", (B, 5, 3, 224, 224))).to(dev)
+    feats = torch.from_numpy(detgen.uniform(f"ddp3f-{rank}", (B, 768), -0.6, 0.6)).to(dev)
+    p0 = m.convnet.flat_params().clone()
+    tr = Trainer(1)
+    local = []
+    for it in range(3):
+        torch.manual_seed(7 + 13 * rank + it)              # shard-local negatives
+        metrics, _ = tr.update(net, (frames, (feats, torch.ones(B))), it)
+        local.append(metrics["full_loss"])
+    torch.cuda.synchronize()
+    out = {"loss": local, "launched": net.sync.launched}
+    for name, p in (("enc", m.convnet.flat_params()), ("head", m.lang_rew.flat_params())):
+        all_p = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(all_p, p.contiguous())
+        out[name + "_identical"] = all(torch.equal(all_p[0], t) for t in all_p)
+    out["moved"] = float((m.convnet.flat_params() - p0).abs().max())
+    out["finite"] = bool(torch.isfinite(m.convnet.flat_params()).all())
+    return out
+
+
+def _steps_worker(rank, world, port, q):
+    _guarded(_steps_rank, rank, world, port, q)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_rccl_parameters_stay_identical_over_three_steps(hip, world):
+    _need_gpus(world)
+    res = _run_ranks(_steps_worker, world)
+    for r, o in res.items():
+        assert o["enc_identical"] and o["head_identical"], (r, o)
+        assert o["launched"] == 3 * 5 and o["moved"] > 0 and o["finite"], (r, o)
+    if world > 1:                                          # different clips per rank: the local losses must differ
+        assert res[0]["loss"] != res[1]["loss"]
+
+
+def _overlap_rank(rank, world, port, frames_per_rank):
+    """Stream-ordering / overlap evidence on a ResNet-50 step: HIP events at the end of each backward stage (compute stream)
+    and at the completion of each slice's all-reduce (an observer stream that joins RCCL's stream right after the enqueue)."""
+    dev = _rccl_init(rank, world, port)
+    from r3m_amd import R3M
+    from r3m_amd.parallel import make_network_wrapper
+    from r3m_amd.trainer import Trainer
+    torch.manual_seed(1)
+    B = frames_per_rank // 5
+    m = R3M("cuda", 1e-4, 1024, size=50, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0).to(dev)
+    net = make_network_wrapper(m, force=True)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frames = torch.randint(0, 256, (B, 5, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
+    tr = Trainer(10 ** 9)
+    for it in range(3):                                    # RCCL sets its channels up lazily: not in the measured step
+        tr.update(net, (frames, [""] * B), it)
+    torch.cuda.synchronize()
+    obs = torch.cuda.Stream(device=dev)
+    stage_ev, ar_ev = {}, {}
+    conv = m.convnet
+    inner = conv._stage_hook
+
+    def stage_hook(stage, off, cnt):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()                                        # fires when this stage's last kernel retires
+        stage_ev[stage] = ev
+        inner(stage, off, cnt)
+
+    def on_launch(idx, sl, work):
+        with torch.cuda.stream(obs):
+            work.wait()                                    # obs joins RCCL's stream for THIS collective
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(obs)
+        ar_ev[idx] = (ev, sl.numel() * 4)
+
+    conv._stage_hook = stage_hook
+    base_idx = net.sync.launched
+    net.sync.on_launch = on_launch
+    net.sync.time_waits(True)
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
+    tr.update(net, (frames, [""] * B), 3)
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    torch.cuda.synchronize()
+    exposed = net.sync.exposed_ms()
+    net.sync.on_launch = None
+    conv._stage_hook = inner
+    t_stage = [base.elapsed_time(stage_ev[k]) for k in range(4)]
+    t_ar = [base.elapsed_time(ar_ev[base_idx + k][0]) for k in range(4)]
+    return {"t_stage_end_ms": t_stage, "t_allreduce_done_ms": t_ar, "slice_bytes": [ar_ev[base_idx + k][1] for k in range(4)],
+            "step_ms": base.elapsed_time(end), "comm_exposed_ms": exposed}
+
+
+def _overlap_worker(rank, world, port, q, frames_per_rank):
+    _guarded(_overlap_rank, rank, world, port, q, frames_per_rank)
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_rccl_allreduce_overlaps_the_remaining_backward(hip, world):
+    """The all-reduce of slice k (sent when backward stage k ends) must be complete before stage k+2 ends: it rides under the
+    backward of the next stages instead of being exposed at the optimizer step."""
+    _need_gpus(world)
+    res = _run_ranks(_overlap_worker, world, 160)
+    lines = []
+    for r in sorted(res):
+        o = res[r]
+        lines.append(f"world {world} rank {r}: step {o['step_ms']:.2f} ms, comm exposed {o['comm_exposed_ms']:.3f} ms; stage ends "
+                     + ", ".join(f"{t:.2f}" for t in o["t_stage_end_ms"]) + " ms; all-reduce done "
+                     + ", ".join(f"{t:.2f}" for t in o["t_allreduce_done_ms"]) + " ms; slice MB "
+                     + ", ".join(f"{b / 1e6:.1f}" for b in o["slice_bytes"]))
+    print("\n".join(lines))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"ddp_overlap_world{world}.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    for r, o in res.items():
+        ts, ta = o["t_stage_end_ms"], o["t_allreduce_done_ms"]
+        assert all(ts[k] < ts[k + 1] for k in range(3)), (r, ts)
+        for k in range(4):
+            assert ta[k] >= ts[k], (r, k, ts, ta)          # a slice cannot be reduced before its stage produced it
+        for k in range(2):
+            assert ta[k] <= ts[k + 2], f"rank {r}: all-reduce of slice {k} finished at {ta[k]:.2f} ms, stage {k+2} ended at {ts[k+2]:.2f} ms"
+        assert o["comm_exposed_ms"] < 0.25 * o["step_ms"], (r, o)
+
+
+def _run_bench(extra, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--size", "18", "--clips-per-gpu", "8",
+           "--prewarm-seconds", "0", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks(hip):
+    """`python bench.py --gpus N` with NO launcher in front (how the driver ran N = 1): N ranks over RCCL, one JSON line.
+    N = min(2, visible GPUs); on a one-GPU box the launcher path is forced for N = 1."""
+    n = min(2, torch.cuda.device_count())
+    out = _run_bench(["--gpus", str(n)] + (["--force-launcher"] if n == 1 else []))
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["value"] > 0
+    assert out["config"]["collectives"].startswith("rccl all_reduce(AVG), 4.0 per step")
+    assert out["config"]["frames_per_gpu"] == 40 and out["scaling"] == "weak"
+    assert out["ms_per_step_rank_min"] <= out["ms_per_step"] == out["ms_per_step_rank_max"]
+    assert out["comm_exposed_ms"] >= 0.0
+    plain = _run_bench(["--gpus", "1"])                    # the one-process form is unchanged: no process group, no RCCL keys
+    assert plain["n_gpus"] == 1 and "rccl_ranks" not in plain and plain["config"]["collectives"] == "none (single process)"

@@ -189,3 +189,51 @@ def test_snapshot_filter_drops_only_frozen_text_keys():
     sd = {"module.convnet.conv1.weight": 1, "module.lang_rew.pred.0.weight": 2, "module.lang_enc.model.embeddings.w": 3,
           "lang_enc.model.x": 4}
     assert list(filter_frozen_text_keys(sd)) == ["module.convnet.conv1.weight", "module.lang_rew.pred.0.weight"]
+
+
+def test_step_predicates_and_timer():
+    from r3m_amd.utils import utils
+    until = utils.Until(3, 1)
+    assert [until(s) for s in range(5)] == [True, True, True, False, False] and utils.Until(None)(10 ** 9)
+    every = utils.Every(4, 1)
+    assert [s for s in range(10) if every(s)] == [0, 4, 8] and not utils.Every(None)(0) and not utils.Every(0)(0)
+    t = utils.Timer()
+    lap, total = t.reset()
+    assert 0 <= lap <= total and t.total_time() >= total
+    utils.set_seed_everywhere(5)
+    a = torch.rand(3)
+    utils.set_seed_everywhere(5)
+    assert torch.equal(a, torch.rand(3))
+
+
+def test_head_without_gradient_is_skipped_like_torch_adam():
+    """zero_grad() must leave the language head with NO gradient until a backward produces one — torch.optim.Adam skips
+    parameters whose .grad is None, and the data-parallel wrapper must not all-reduce a stale buffer."""
+    from r3m_amd import R3M
+    m = R3M("cpu", 1e-4, 64, size=18, langweight=1.0, tcnweight=1.0)
+    head = m.lang_rew
+    assert not head.has_grads()
+    head._has_grads = True                                  # what a backward through the head leaves behind
+    m.encoder_opt.zero_grad()
+    assert not head.has_grads() and head._grad_fresh
+
+
+def test_optimizer_state_of_another_owner_set_is_refused():
+    """a snapshot saved with langweight=0 (one flat buffer) resumed into a model with a language head (two), or the
+    reverse, must fail clearly instead of mis-assigning moments / step counters."""
+    from r3m_amd import R3M
+    enc_only = R3M("cpu", 1e-4, 64, size=18, langweight=0.0, tcnweight=1.0)
+    with_head = R3M("cpu", 1e-4, 64, size=18, langweight=1.0, tcnweight=1.0)
+    sd1, sd2 = enc_only.encoder_opt.state_dict(), with_head.encoder_opt.state_dict()
+    assert len(sd1["steps"]) == 1 and len(sd2["steps"]) == 2
+    with pytest.raises(ValueError, match="different langweight"):
+        with_head.encoder_opt.load_state_dict(sd1)
+    with pytest.raises(ValueError, match="different langweight"):
+        enc_only.encoder_opt.load_state_dict(sd2)
+    with_head.encoder_opt.load_state_dict(sd2)              # the matching one loads
+    bad = dict(sd1, exp_avg=[torch.zeros(8)], exp_avg_sq=[torch.zeros(8)])
+    with pytest.raises(ValueError, match="elements"):
+        enc_only.encoder_opt.load_state_dict(bad)
+    old = {"step": 4, "exp_avg": [None], "exp_avg_sq": [None], "param_groups": sd1["param_groups"]}   # round-1 layout: one shared step
+    enc_only.encoder_opt.load_state_dict(old)
+    assert enc_only.encoder_opt._steps == [4]
