@@ -972,13 +972,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // =====================================================================================================
-// wgrad, direct-to-LDS staging. Same GEMM as wgrad_kernel; the [k][channel] LDS image is lane-linear (a row of 64 or 128
-// floats = 256/512 B, one DMA instruction covers 4 or 2 consecutive k rows), so no swizzle is needed and the b32 fragment
-// reads stay conflict-free. Two stages, one barrier per K step, the K loop unrolled by two so stage offsets are
-// immediates. The dY operand and the X operand of 1x1/stride-1 convs advance by a constant 32 rows per step (one 64-bit
-// add per DMA); only the X operand of 3x3 / strided convs keeps a per-step (oy, ox) walk. Rows past the end of the split
-// and padding taps read the zero buffer.
+// wgrad, direct-to-LDS staging through BUFFER addressing (round 3). Same GEMM as the register-staged probe kernel; the
+// [k][channel] LDS image is lane-linear (a row of 64 or 128 floats = 256/512 B, one DMA instruction covers 4 or 2 consecutive
+// k rows), so no swizzle is needed and the b32 fragment reads stay conflict-free. Two stages, one barrier per K step.
+//
+// Why buffer addressing: on gfx950 the f32-input MFMA shares the SIMD's fp32 lanes with the VALU, so every vector
+// instruction in the K loop costs matrix time. `global_load_lds` needs a 64-bit per-lane address, i.e. per DMA
+// piece a 64-bit add, the (oy, ox) walk, four compares and a pointer select in VALU — ~25 vector instructions per X piece of a
+// 3x3 convolution, ~125 per 64 MFMAs. `buffer_load_dwordx4 ... lds` takes a wave-uniform 128-bit descriptor (base, bytes) in
+// SGPRs plus a 32-bit per-lane offset, and lanes whose offset is >= the descriptor's byte count land ZEROS in LDS
+// (tools/micro/bufload.hip). So:
+//   * dY, and X of 1x1/stride-1 convolutions (rows are linear in m): the per-lane offset is a CONSTANT; a K step advances the
+//     descriptor base by 32 rows and shrinks its byte count with four scalar instructions — rows past the end of the split
+//     fall off the descriptor and read zeros. No vector instruction per piece at all.
+//   * X of 3x3 / strided convolutions: a DMA instruction covers only 2 (128-wide tile) or 4 (64-wide) consecutive rows m, and
+//     which rows is wave-uniform — the (frame, oy, ox) walk, the tap shift and the padding test of every staged row run on the
+//     SCALAR unit (in the shadow of the MFMAs); a padding row gets an out-of-range offset. Per lane: pick its row's scalar
+//     offset and add the channel offset = 3 (or 6) vector instructions per piece.
 // =====================================================================================================
+constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count below: such a lane's 16 bytes arrive as zeros
+
+// One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
+// descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
+// builtin and would silently drop the kernels that call it).
+__device__ __forceinline__ void buf_dma16(const void* base, int bytes, float* lds, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000 /* raw, 32-bit */),
+                                           (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+#endif
+}
+
 template <int BMt, int BNt>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BK = 32;
@@ -1006,96 +1029,112 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   const int me = min(p.M, ms + p.rows_per_split);
   const int hw = p.Ho * p.Wo;
 
-  // lane -> (k row within the instruction, first channel)
+  // lane -> (k row within the instruction, first channel); the per-lane offsets below never change in the K loop
   const int a_k = lane / (BMt / 4), a_c = (lane % (BMt / 4)) * 4;
   const int b_k = lane / (BNt / 4), b_c = (lane % (BNt / 4)) * 4;
-  const bool a_cv = (co0 + a_c) < p.Co, b_cv = (ci0 + b_c) < p.Ci;
-  const float* zl = g_zero_line + (lane & 7) * 4;
+  const unsigned a_chan = (co0 + a_c) < p.Co ? (unsigned)a_c * 4u : BUF_OOB;
+  const unsigned b_chan = (ci0 + b_c) < p.Ci ? (unsigned)b_c * 4u : BUF_OOB;
 
-  // A operand (dY): row of instruction j at K step 0
-  int a_m[AJ];
-  const float* a_ptr[AJ];
+  // A operand (dY): descriptor = [row ms + 32*step, end of the split) x channels from co0
+  const float* a_base = p.dY + (long long)ms * p.Co + co0;
+  int a_left = (int)(((long long)(me - ms) * p.Co - co0) * 4);      // bytes (host: a split spans < 2 GB)
+  const int a_stepb = 32 * p.Co * 4;
+  unsigned a_voff[AJ];
 #pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    a_m[j] = ms + wave_s * 8 + j * A_RPI + a_k;
-    a_ptr[j] = p.dY + (long long)a_m[j] * p.Co + (a_cv ? co0 + a_c : 0);
-  }
+  for (int j = 0; j < AJ; ++j) a_voff[j] = (unsigned)((wave_s * 8 + j * A_RPI + a_k) * p.Co) * 4u + a_chan;
+
   // B operand (X)
-  const int q32 = 32 / p.Wo, r32 = 32 - q32 * p.Wo;
-  const bool fast_adv = (q32 + 1) <= p.Ho;
   const long long img = (long long)p.Hi * p.Wi * p.Ci;
-  int b_m[BJ];
-  const float* b_ptr[BJ];   // simple rows: running pointer; otherwise image base pointer of the row's frame
-  int xoy[BJ], xox[BJ];
+  const float* b_base;
+  int b_left;
+  const int b_stepb = 32 * p.Ci * 4;
+  unsigned b_voff[BJ];             // simple rows: constant per-lane offsets
+  // non-simple rows: ONE scalar cursor (frame offset, oy, ox) that walks the 8 consecutive rows this wave stages per K step,
+  // then jumps the 24 rows to its rows of the next step; `c_left` = rows from the cursor to the end of the split
+  int c_ox = 0, c_oy = 0, c_left = 0;
+  unsigned c_f = 0;                // byte offset of the cursor row's frame from b_base
+  const int q24 = 24 / p.Wo, r24 = 24 - q24 * p.Wo;
+  const unsigned imgb = (unsigned)(img * 4);
+  const int kh_p = kh - p.pad, kw_p = kw - p.pad;
+  if (p.simple_rows) {
+    b_base = p.X + (long long)ms * p.Ci + ci0;
+    b_left = (int)(((long long)(me - ms) * p.Ci - ci0) * 4);
 #pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    b_m[j] = ms + wave_s * 8 + j * B_RPI + b_k;
-    xoy[j] = 0; xox[j] = 0;
-    if (p.simple_rows) {
-      b_ptr[j] = p.X + (long long)b_m[j] * p.Ci + (b_cv ? ci0 + b_c : 0);
-    } else {
-      const int n = b_m[j] / hw;
-      const int rem = b_m[j] - n * hw;
-      xoy[j] = rem / p.Wo;
-      xox[j] = rem - xoy[j] * p.Wo;
-      b_ptr[j] = p.X + (long long)n * img + (b_cv ? ci0 + b_c : 0);
-    }
+    for (int j = 0; j < BJ; ++j) b_voff[j] = (unsigned)((wave_s * 8 + j * B_RPI + b_k) * p.Ci) * 4u + b_chan;
+  } else {
+    const int n0 = ms / hw;        // first frame of the split: 32-bit offsets are relative to it
+    b_base = p.X + (long long)n0 * img + ci0;
+    const long long rest = ((long long)(p.N - n0) * img - ci0) * 4;
+    b_left = rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) b_voff[j] = 0;
+    const int m = ms + wave_s * 8;
+    const int n = m / hw;
+    const int rem = m - n * hw;
+    c_oy = rem / p.Wo;
+    c_ox = rem - c_oy * p.Wo;
+    c_f = (unsigned)(n - n0) * imgb;
+    c_left = me - m;
   }
-  const long long a_step = 32LL * p.Co, b_step = 32LL * p.Ci;
+  bool b_is[B_RPI];                // lane masks: "my row is sub-row r of the instruction"
+#pragma unroll
+  for (int r = 0; r < B_RPI; ++r) b_is[r] = (b_k == r);
 
-  auto sel = [](const float* s, const float* z, bool ok) {
-    const unsigned long long msk = ok ? ~0ull : 0ull;
-    return reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(s) & msk) |
-                                          (reinterpret_cast<unsigned long long>(z) & ~msk));
-  };
-  // one DMA piece (pc < AJ: dY rows, else X rows) of the K step whose first row is (a_m / b_m); advances that piece's
-  // descriptor by 32 rows
+  // one DMA piece (pc < AJ: dY rows, else X rows) into `stage`
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       float* la = smem + stage * STAGE + wave_s * 8 * BMt;
-      const float* src = sel(a_ptr[j], zl, (a_m[j] < me) && a_cv);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(la + j * A_RPI * BMt), 16, 0, 0);
-      a_m[j] += 32;
-      a_ptr[j] += a_step;
+      buf_dma16(a_base, a_left, la + j * A_RPI * BMt, a_voff[j]);
     } else {
       constexpr int j = pc - AJ;
       float* lb = smem + stage * STAGE + BK * BMt + wave_s * 8 * BNt;
-      const float* src;
+      unsigned voff;
       if (p.simple_rows) {
-        src = sel(b_ptr[j], zl, (b_m[j] < me) && b_cv);
-        b_ptr[j] += b_step;
+        voff = b_voff[j];
       } else {
-        const int iy = xoy[j] * p.stride + kh - p.pad, ix = xox[j] * p.stride + kw - p.pad;
-        const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (b_m[j] < me) && b_cv;
-        src = sel(b_ptr[j] + ((long long)iy * p.Wi + ix) * p.Ci, zl, in);   // never dereferenced when out of the image
-        if (fast_adv) {
-          int ox = xox[j] + r32, oy = xoy[j] + q32;
-          const bool cx = ox >= p.Wo;
-          ox = cx ? ox - p.Wo : ox;
-          oy = cx ? oy + 1 : oy;
-          const bool cy = oy >= p.Ho;
-          oy = cy ? oy - p.Ho : oy;
-          b_ptr[j] = cy ? b_ptr[j] + img : b_ptr[j];
-          xox[j] = ox; xoy[j] = oy;
-        } else {
-          const int m = b_m[j] + 32;
-          const int n = m / hw;
-          const int rem = m - n * hw;
-          xoy[j] = rem / p.Wo;
-          xox[j] = rem - xoy[j] * p.Wo;
-          b_ptr[j] = p.X + (long long)n * img + (b_cv ? ci0 + b_c : 0);
+        unsigned so[B_RPI];
+#pragma unroll
+        for (int r = 0; r < B_RPI; ++r) {     // scalar unit: tap shift, padding test, row offset, cursor to the next row
+          const int iy = c_oy * p.stride + kh_p, ix = c_ox * p.stride + kw_p;
+          const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (c_left > 0);
+          so[r] = in ? c_f + (unsigned)((iy * p.Wi + ix) * p.Ci) * 4u : BUF_OOB;
+          c_left -= 1;
+          c_ox += 1;
+          if (c_ox == p.Wo) {
+            c_ox = 0;
+            c_oy += 1;
+            if (c_oy == p.Ho) { c_oy = 0; c_f += imgb; }
+          }
         }
+        if constexpr (j == BJ - 1) {          // the wave's 8 rows of this K step are issued: jump to its rows of the next one
+          c_left -= 24;
+          c_ox += r24;
+          if (c_ox >= p.Wo) { c_ox -= p.Wo; c_oy += 1; }
+          c_oy += q24;
+          while (c_oy >= p.Ho) { c_oy -= p.Ho; c_f += imgb; }
+        }
+        voff = so[0];
+#pragma unroll
+        for (int r = 1; r < B_RPI; ++r) voff = b_is[r] ? so[r] : voff;
+        voff += b_chan;
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lb + j * B_RPI * BNt), 16, 0, 0);
-      b_m[j] += 32;
+      buf_dma16(b_base, b_left, lb + j * B_RPI * BNt, voff);
+    }
+  };
+  // after the last piece of a K step: both descriptors move on by 32 rows (scalar)
+  auto advance = [&]() __attribute__((always_inline)) {
+    a_base += 32 * p.Co;
+    a_left = a_left > a_stepb ? a_left - a_stepb : 0;
+    if (p.simple_rows) {
+      b_base += 32 * p.Ci;
+      b_left = b_left > b_stepb ? b_left - b_stepb : 0;
     }
   };
   auto issue = [&](int stage) __attribute__((always_inline)) {
     static_for<AJ + BJ>([&](auto pc_c) __attribute__((always_inline)) { issue_piece(stage, pc_c); });
+    advance();
   };
 
   f32x16 acc[TM][TN];
@@ -1136,6 +1175,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
         if (dma_stage >= 0) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(dma_stage, std::integral_constant<int, kk / EVERY>{});
+          if constexpr (kk / EVERY == NP - 1) advance();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1499,10 +1539,21 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
   R3M_REQUIRE(splitK >= 1, "wgrad: splitK=%d", splitK);
   p.rows_per_split = ((p.M + splitK - 1) / splitK + 31) / 32 * 32;
   R3M_REQUIRE(ceil_div(p.M, p.rows_per_split) == splitK, "wgrad: splitK=%d does not tile M=%d", splitK, p.M);
+  {   // buffer addressing: a block's operands are reached through 32-bit offsets from the first row / frame of its split
+    const long long lim = 0x7FFFF000LL;
+    const long long a_span = (long long)p.rows_per_split * p.Co * 4;
+    const long long frames = (long long)p.rows_per_split / ((long long)p.Ho * p.Wo) + 2;
+    const long long b_span = p.simple_rows ? (long long)p.rows_per_split * p.Ci * 4 : frames * p.Hi * p.Wi * p.Ci * 4;
+    R3M_REQUIRE(a_span < lim && b_span < lim, "wgrad: one split spans %lld / %lld bytes (limit 2 GiB): raise splitK (%d)", a_span, b_span, splitK);
+  }
   const int T = p.KH * p.KW;
   {
-    const int il = R3M_ENV_INT("R3M_WG_INTERLEAVE", 0);
-    p.interleave = il;
+    // DMA pieces spread between the MFMAs (one per 2 K pairs) or issued in one burst before them. Round 3, buffer addressing,
+    // same box (profiles/r03_wgrad_buffer_ab.txt): spreading wins where a piece carries scalar work — the (oy, ox) walk of 3x3 /
+    // strided X rows on a 128-wide tile (115.8 -> 118-123 TFLOP/s) — and loses where it does not (1x1: 134 -> 130) and on the
+    // 64-wide tile (107.5 -> 100). Probe builds: R3M_WG_INTERLEAVE = 0 / 1 forces it.
+    const int il = R3M_ENV_INT("R3M_WG_INTERLEAVE", -1);
+    p.interleave = il >= 0 ? il : (!p.simple_rows && wg_wide(p.Co, p.Ci));
     const int xc = R3M_ENV_INT("R3M_WG_XCD", 1);
     p.xcd = xc;
   }
