@@ -990,18 +990,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 //     SCALAR unit (in the shadow of the MFMAs); a padding row gets an out-of-range offset. Per lane: pick its row's scalar
 //     offset and add the channel offset = 3 (or 6) vector instructions per piece.
 // =====================================================================================================
-constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count below: such a lane's 16 bytes arrive as zeros
-
-// One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
-// descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
-// builtin and would silently drop the kernels that call it).
-__device__ __forceinline__ void buf_dma16(const void* base, int bytes, float* lds, unsigned voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000 /* raw, 32-bit */),
-                                           (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
-#endif
-}
-
 template <int BMt, int BNt>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BK = 32;
@@ -1235,7 +1223,11 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
 // a per-lane base plus an immediate — no address arithmetic in the K loop. K is walked as 7 x 22 (j = 21 multiplies a
 // zero weight), i.e. 154 instead of 147 MACs per output: 5 % padding instead of im2col's 160.
 // =====================================================================================================
-constexpr int ST_PS = 692;      // patch row stride: 230 pixels x 3 channels (+2 pad)
+constexpr int ST_PS = 692;      // patch row stride (forward): 230 pixels x 3 channels (+2 pad)
+constexpr int ST_PSW = 694;     // patch row stride (weight gradient): == 22 (mod 32). There 32 lanes read patch[kh * stride + jj] for 32
+                                // CONSECUTIVE k = 22 kh + jj, which cross a kernel-row boundary; with 692 (== 20 mod 32) the lanes of
+                                // the next kernel row landed on the banks of jj = 20, 21 (2-way conflict on every B read: PMC
+                                // lds_conflict_frac 0.44, round 2); with 694 the bank is k mod 32 — conflict-free
 constexpr int ST_KS = 155;      // LDS weight row stride (odd: conflict-free fragment reads)
 constexpr int ST_K = 154;       // 7 kernel rows x 22
 
@@ -1290,17 +1282,19 @@ int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s) {
 }
 
 // stage `nrows` input rows iy0.. of frame f into patch[y][9 zeros | 672 data | zeros]: float4 row copies
+template <int PS = ST_PS>
 __device__ __forceinline__ void stem_load_patch(const float* __restrict__ xn, float* patch, long long f, int iy0, int nrows) {
-  for (int i = threadIdx.x; i < nrows * 20; i += 256) {
-    const int y = i / 20, e = i - y * 20;
-    patch[y * ST_PS + (e < 9 ? e : 672 + e)] = 0.f;
+  constexpr int TAIL = PS - 681;      // zero floats behind the 672 data floats (9 in front)
+  for (int i = threadIdx.x; i < nrows * (9 + TAIL); i += 256) {
+    const int y = i / (9 + TAIL), e = i - y * (9 + TAIL);
+    patch[y * PS + (e < 9 ? e : 672 + e)] = 0.f;
   }
   for (int i = threadIdx.x; i < nrows * 168; i += 256) {
     const int y = i / 168, q = i - y * 168;
     const int iy = iy0 + y;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)iy < 224u) v = ldg4(xn + ((f * 224 + iy) * 224) * 3 + q * 4);
-    float* d = patch + y * ST_PS + 9 + q * 4;     // 9-float left border: not 16-byte aligned -> scalar LDS stores
+    float* d = patch + y * PS + 9 + q * 4;        // 9-float left border: not 16-byte aligned -> scalar LDS stores
     d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
   }
 }
@@ -1393,9 +1387,9 @@ int launch_stem_fwd(const float* x_nchw, const float* w147, void* y, float* stat
 template <class T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dY,
                                                           float* __restrict__ partial, int total_rows) {
-  __shared__ __attribute__((aligned(16))) float smem[7 * ST_PS + 112 * 64];
-  float* patch = smem;
-  float* dys = smem + 7 * ST_PS;
+  __shared__ __attribute__((aligned(16))) float smem[112 * 64 + 7 * ST_PSW];
+  float* dys = smem;                  // 16-byte aligned (float4 stores); the patch takes scalar stores
+  float* patch = smem + 112 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
   const int lrow = lane & 31, lh = lane >> 5;
@@ -1407,7 +1401,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     int j = (jt0 + t) * 32 + lrow;
     if (j >= ST_K) j = 0;                       // columns 154..159 (and the unused third tile of the second wave column)
     const int kh = j / 22, jj = j - kh * 22;
-    b_base[t] = kh * ST_PS + jj + 6 * lh;
+    b_base[t] = kh * ST_PSW + jj + 6 * lh;
   }
   // two-level summation: `acc` covers one image row (112 products per element), `tot` adds the rows — short fp32 chains
   f32x16 acc[3], tot[3];
@@ -1423,7 +1417,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const long long f = row / 112;
     const int oy = row - (int)f * 112;
-    stem_load_patch(x, patch, f, 2 * oy - 3, 7);
+    stem_load_patch<ST_PSW>(x, patch, f, 2 * oy - 3, 7);
     const T* src = dY + (long long)row * 112 * 64;
     for (int i = tid; i < 112 * 16; i += 256) *reinterpret_cast<f32x4*>(dys + i * 4) = ld4t(src + i * 4);
     __syncthreads();

@@ -471,6 +471,19 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
   }
 }
 
+// ---- LDS DMA through a buffer descriptor (round 3; see the wgrad kernels) ----
+constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count below: such a lane's 16 bytes arrive as zeros
+
+// One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
+// descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
+// builtin and would silently drop the kernels that call it).
+__device__ __forceinline__ void buf_dma16(const void* base, int bytes, void* lds, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000 /* raw, 32-bit */),
+                                           (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+#endif
+}
+
 // per-thread descriptor of one staged A row: image base offset + top-left input pixel of the GEMM row
 struct RowDesc {
   long long base;
