@@ -560,29 +560,38 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
 // lane 4j + (c >> 2) addressed, for j = 0..3. With lane q = 4j + i addressing k row kb + j, channels cb + 4i..4i+3, lane c
 // receives channel cb + c at k = kb..kb+3: four consecutive k of one channel — half an MFMA operand.
 // =====================================================================================================
-template <int BMt, int BNt, int BK = 64>   // BK = rows per K step: 64, or 32 (half the LDS: more blocks per CU)
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
+// NT = 3 (round 3, "kernel-row" blocks of a 3-wide kernel): one block owns the THREE taps (kh, 0..2) of one kernel row for its
+// (co, ci) tile — three accumulator sets (192 registers on the 128 x 128 tile). The dY tile of a K step is staged ONCE and its
+// fragments are read ONCE for the three taps, the (oy, ox) walk of the staged X rows is shared (the taps differ by one pixel
+// in x), and each tap still stages its own exactly-masked X rows (no register masks, any width / stride). Per tap this is 2/3 of
+// the L2 -> LDS bytes (the bf16 128 x 128 tile needs ~39 TB/s of that path at the matrix peak; the chip delivers ~17), 2/3 of
+// the DMA instructions and 2/3 of the LDS fragment reads of the per-tap form.
+template <int BMt, int BNt, int BK = 64, int NT = 1>   // BK = rows per K step: 64, or 32 (half the LDS: more blocks per CU)
+__global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const WgradParams p) {
   static_assert(BK == 64 || BK == 32, "K step of 64 or 32 rows");
+  static_assert(NT == 1 || NT == 3, "one tap, or the three taps of a kernel row");
   constexpr int WR = BK / 4;                                   // k rows staged per wave per stage
   constexpr int TM = BMt / 64, TN = BNt / 64;
   constexpr int A_ROWB = BMt * 2, B_ROWB = BNt * 2;            // bytes per k row
   constexpr int A_RPI = 1024 / A_ROWB, B_RPI = 1024 / B_ROWB;  // k rows per DMA instruction
-  constexpr int AJ = WR / A_RPI, BJ = WR / B_RPI;              // instructions per wave per stage
-  constexpr int NP = AJ + BJ;
-  constexpr int STAGE = BK * (A_ROWB + B_ROWB);
+  constexpr int AJ = WR / A_RPI, BJ = WR / B_RPI;              // instructions per wave per stage (per tap for B)
+  constexpr int NP = AJ + BJ;                                  // piece GROUPS: a B group issues NT instructions
+  constexpr int B_TILE = BK * B_ROWB;
+  constexpr int STAGE = BK * A_ROWB + NT * B_TILE;
   __shared__ __attribute__((aligned(256))) unsigned char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int T = p.KH * p.KW;
+  const int TG = T / NT;                                       // tap groups per tile (NT = 3: kernel rows)
   const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int bx = lid % p.gx, by = lid / p.gx;   // by = split index: consecutive logical blocks read the same rows
-  const int tap = bx % T;
-  const int tile = bx / T;
+  const int tap0 = (bx % TG) * NT;
+  const int tile = bx / TG;
   const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
   const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int kh = tap0 / p.KW, kw0 = tap0 - kh * p.KW;
   const int ms = by * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   const int hw = p.Ho * p.Wo;
@@ -628,6 +637,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
     }
   }
   const long long a_step = (long long)BK * p.Co * 2, b_step = (long long)BK * p.Ci * 2;
+  const int pixb = p.Ci * 2;                                    // bytes between the X rows of neighbouring taps (one pixel)
 
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
@@ -640,14 +650,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
     } else {
       constexpr int j = pc - AJ;
       unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * WR + j * B_RPI) * B_ROWB;
-      const char* src;
       if (p.simple_rows) {
-        src = sel_ptr(b_ptr[j], zl, b_m[j] < me);
+        dma16(sel_ptr(b_ptr[j], zl, b_m[j] < me), lb);
         b_ptr[j] += b_step;
       } else {
-        const int iy = xoy[j] * p.stride + kh - p.pad, ix = xox[j] * p.stride + kw - p.pad;
-        const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (b_m[j] < me);
-        src = sel_ptr(b_ptr[j] + ((long long)iy * p.Wi + ix) * p.Ci * 2, zl, in);   // never dereferenced when out of the image
+        const int iy = xoy[j] * p.stride + kh - p.pad, ix0 = xox[j] * p.stride + kw0 - p.pad;
+        const bool rowok = ((unsigned)iy < (unsigned)p.Hi) && (b_m[j] < me);
+        const char* src0 = b_ptr[j] + ((long long)iy * p.Wi + ix0) * p.Ci * 2;   // never dereferenced when out of the image
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bool in = rowok && ((unsigned)(ix0 + t) < (unsigned)p.Wi);
+          dma16(sel_ptr(src0 + t * pixb, zl, in), lb + t * B_TILE);
+        }
         if (fast_adv) {
           int ox = xox[j] + r64, oy = xoy[j] + q64;
           const bool cx = ox >= p.Wo;
@@ -666,18 +680,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
           b_ptr[j] = Xb + (long long)n * img + b_cb;
         }
       }
-      dma16(src, lb);
       b_m[j] += BK;
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[NT][TM][TN];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
 
   // transpose-read addressing. Lane l: group-local q = l & 15 addresses k row 8*(l>>5) + (q>>2) (+16s + 4r as an immediate),
   // channels [16*((l>>4)&1) + 4*(q&3), +4) of its MFMA tile; the tile's 64-byte group index is XORed with the row key.
@@ -708,11 +723,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
     if (dma_stage >= 0 && !p.interleave) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(dma_stage, pc); });
     static_for<BK / 16>([&](auto s_c) __attribute__((always_inline)) {
       constexpr int sidx = decltype(s_c)::value;
-      bf16x8 a[TM], b[TN];
+      bf16x8 a[TM];
 #pragma unroll
       for (int t = 0; t < TM; ++t) a[t] = frag(st + fa_off[t], A_ROWB, sidx);
-#pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = frag(st + fb_off[t], B_ROWB, sidx);
       if (dma_stage >= 0 && p.interleave) {
         constexpr int P0 = sidx * NP / (BK / 16), P1 = (sidx + 1) * NP / (BK / 16);
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
@@ -720,10 +733,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
         });
       }
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tp = 0; tp < NT; ++tp) {
+        bf16x8 b[TN];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int t = 0; t < TN; ++t) b[t] = frag(st + tp * B_TILE + fb_off[t], B_ROWB, sidx);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tp][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tp][tm][tn], 0, 0, 0);
+      }
     });
   };
 
@@ -739,16 +758,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
   float* out = p.out + (long long)by * p.Co * T * p.Ci;
   const int lrow = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
-        out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
+          out[((long long)co * T + tap0 + tp) * p.Ci + ci] = acc[tp][tm][tn][r];
+        }
       }
-    }
 }
 
 // =====================================================================================================
@@ -935,6 +956,13 @@ static bool wgrad_halo_eligible(const WgradParams& p) {
 
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
 
+// Round 3: 3-wide kernels on the 128 x 128 tile run one block per KERNEL ROW (three taps, dY staged and read once): ResNet-34's
+// 128 / 256 / 512-channel 3x3 weight gradients, stride 1 and 2. R3M_WG16_ROWS=0 (probe builds): per-tap blocks.
+static bool wg16_rows(int KW, bool wide) {
+  const int v = R3M_ENV_INT("R3M_WG16_ROWS", 1);
+  return v && wide && KW == 3;
+}
+
 // split-K factor: enough blocks to fill the chip ~4 (wide) / ~10 (narrow) times, rows per split a multiple of 64
 int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   const bool wide = wg_wide(Co, Ci);
@@ -942,7 +970,9 @@ int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   const int tgt = R3M_ENV_INT("R3M_WG16_BLOCKS", 0);
   // the all-taps kernel runs one block per (tile, split) for all nine taps: 512 splits of the 64-channel layers fill the chip
   const int narrow_target = (T == 9 && wg16_halo()) ? 512 * 9 : 2560;
-  int split = (wide ? (tgt > 0 ? tgt : 1024) : narrow_target) / (tiles > 0 ? tiles : 1);
+  int blocks_per_split = tiles > 0 ? tiles : 1;
+  if (wg16_rows(T == 9 ? 3 : 0, wide)) blocks_per_split = tiles / 3;     // `tiles` counts taps; a kernel-row block covers three
+  int split = (wide ? (tgt > 0 ? tgt : 1024) : narrow_target) / blocks_per_split;
   const int max_split = ceil_div(M, 256);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -977,11 +1007,18 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
     prof_end(s);
     return check_launch("wgrad3x3_halo_bf16");
   }
-  const dim3 grid(p.gx * splitK);
   // K steps of 32 rows for the 128x128 tile (32 KB of stages instead of 64: -16 % measured over ResNet-50), 64 rows for the
   // 64x64 tile (32 rows measured +5 % there). R3M_WG16_BK=64 / =32 forces one step size on both (experiments).
   const int bk = R3M_ENV_INT("R3M_WG16_BK", 0);
   const bool bk32 = bk == 32 || (bk != 64 && wide);
+  if (wg16_rows(p.KW, wide)) {   // 3-wide kernels on the 128 x 128 tile: one block = the three taps of a kernel row
+    p.gx = tilesM * p.tilesN * p.KH;
+    hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32, 3>), dim3(p.gx * splitK), dim3(256), 0, s, p);
+    prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
+    prof_end(s);
+    return check_launch("wgrad_bf16 (kernel rows)");
+  }
+  const dim3 grid(p.gx * splitK);
   if (wide && bk32) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32>), grid, dim3(256), 0, s, p);
   else if (wide) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, s, p);
   else if (bk32) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64, 32>), grid, dim3(256), 0, s, p);

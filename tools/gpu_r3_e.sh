@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: buffer-addressed bf16 wgrad — op parity, per-shape A/B vs the HEAD build (ResNet-34 at 2560 frames, ResNet-50 at 1280), configs[4]/[2] steps
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_bf16.py -m gpu -q -x -k "wgrad or conv or op" -p no:cacheprovider 2>&1 | tail -4
+timeout 1500 python -m pytest tests/test_gpu_bf16.py -m gpu -q -x -k "not headline" -p no:cacheprovider 2>&1 | tail -4
 S34="2560,28,128,128,3,1,1 2560,14,256,256,3,1,1 2560,7,512,512,3,1,1 2560,56,64,128,3,2,1 2560,28,128,256,3,2,1 2560,14,256,512,3,2,1 2560,56,64,128,1,2,0"
 S50="1280,14,256,1024,1,1,0 1280,14,1024,256,1,1,0 1280,28,128,512,1,1,0 1280,28,512,128,1,1,0 1280,14,256,256,3,1,1 1280,56,256,512,1,2,0 1280,7,2048,512,1,1,0"
 for rep in 1 2; do
