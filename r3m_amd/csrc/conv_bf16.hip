@@ -605,62 +605,76 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
   const int b_k = lane / (B_ROWB / 16), b_ps = lane % (B_ROWB / 16);
   const int a_key = (BMt == 128) ? (a_k & 3) : ((a_k >> 1) & 1);
   const int b_key = (BNt == 128) ? (b_k & 3) : ((b_k >> 1) & 1);
-  const int a_cb = (co0 + (a_ps ^ (4 * a_key)) * 8) * 2;       // byte offset of this lane's 8 channels inside a dY row
-  const int b_cb = (ci0 + (b_ps ^ (4 * b_key)) * 8) * 2;
-  const char* zl = reinterpret_cast<const char*>(g_zero_bytes) + (lane & 15) * 16;
+  // Round 3: LDS DMA through buffer descriptors (conv_dev.h, buf_dma16). PMC on the ResNet-34 3x3 layers showed this kernel
+  // ISSUE-bound, not bandwidth-bound: 6.8 vector instructions per MFMA (the per-lane 64-bit source pointers of global_load_lds:
+  // 64-bit multiply-adds, pointer selects, a 64-bit advance per piece), waves 28 % issuing / 35 % stalled on dependent VALU / 37 %
+  // parked, matrix pipe busy 0.37. With a descriptor the per-lane part is a 32-bit byte offset and out-of-range lanes read zeros:
+  //   dY (and X of 1x1 stride-1 layers): CONSTANT per-lane offsets, the descriptor advances one K step on the scalar unit and
+  //     rows past the split fall off its end — no vector instruction per piece;
+  //   X of 3x3 / strided layers: per-lane (oy, ox, frame offset) walk in 32-bit arithmetic, padding taps get an out-of-range
+  //     offset; rows past the split need no test (their dY rows are zeros).
+  const unsigned a_chan = (unsigned)((co0 + (a_ps ^ (4 * a_key)) * 8) * 2);   // byte offset of this lane's 8 channels inside a dY row
+  const unsigned b_chan = (unsigned)((ci0 + (b_ps ^ (4 * b_key)) * 8) * 2);
 
-  int a_m[AJ];
-  const char* a_ptr[AJ];
+  const char* a_base = dYb + (long long)ms * p.Co * 2;          // descriptor: rows [ms + BK * step, me) of dY
+  int a_left = (int)((long long)(me - ms) * p.Co * 2);
+  const int a_stepb = BK * p.Co * 2;
+  unsigned a_voff[AJ];
 #pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    a_m[j] = ms + wave * WR + j * A_RPI + a_k;
-    a_ptr[j] = dYb + (long long)a_m[j] * p.Co * 2 + a_cb;
-  }
+  for (int j = 0; j < AJ; ++j) a_voff[j] = (unsigned)((wave * WR + j * A_RPI + a_k) * p.Co * 2) + a_chan;
+
   const int q64 = BK / p.Wo, r64 = BK - q64 * p.Wo;          // (oy, ox) advance of one K step
   const bool fast_adv = (q64 + 1) <= p.Ho;
   const long long img = (long long)p.Hi * p.Wi * p.Ci * 2;
+  const unsigned imgb = (unsigned)img;
+  const int n0 = ms / hw;                                     // 3x3 / strided: offsets are relative to the split's first frame
+  const char* b_base = p.simple_rows ? Xb + (long long)ms * p.Ci * 2 : Xb + (long long)n0 * img;
+  int b_left;
+  {
+    const long long rest = p.simple_rows ? (long long)(me - ms) * p.Ci * 2 : (long long)(p.N - n0) * img;
+    b_left = rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB;
+  }
+  const int b_stepb = BK * p.Ci * 2;
   int b_m[BJ];
-  const char* b_ptr[BJ];   // simple rows: running pointer; otherwise image base pointer of the row's frame
+  unsigned b_off[BJ];      // simple rows: constant per-lane offset; otherwise byte offset of the row's frame from b_base (+ channels)
   int xoy[BJ], xox[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     b_m[j] = ms + wave * WR + j * B_RPI + b_k;
     xoy[j] = 0; xox[j] = 0;
     if (p.simple_rows) {
-      b_ptr[j] = Xb + (long long)b_m[j] * p.Ci * 2 + b_cb;
+      b_off[j] = (unsigned)((wave * WR + j * B_RPI + b_k) * p.Ci * 2) + b_chan;
     } else {
       const int n = b_m[j] / hw;
       const int rem = b_m[j] - n * hw;
       xoy[j] = rem / p.Wo;
       xox[j] = rem - xoy[j] * p.Wo;
-      b_ptr[j] = Xb + (long long)n * img + b_cb;
+      b_off[j] = (unsigned)(n - n0) * imgb + b_chan;
     }
   }
-  const long long a_step = (long long)BK * p.Co * 2, b_step = (long long)BK * p.Ci * 2;
   const int pixb = p.Ci * 2;                                    // bytes between the X rows of neighbouring taps (one pixel)
+  const int rowb = p.Wi * pixb;
+  const int kh_p = kh - p.pad, kw_p = kw0 - p.pad;
 
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       unsigned char* la = smem + stage * STAGE + (wave * WR + j * A_RPI) * A_ROWB;
-      dma16(sel_ptr(a_ptr[j], zl, a_m[j] < me), la);
-      a_m[j] += BK;
-      a_ptr[j] += a_step;
+      buf_dma16(a_base, a_left, la, a_voff[j]);
     } else {
       constexpr int j = pc - AJ;
       unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * WR + j * B_RPI) * B_ROWB;
       if (p.simple_rows) {
-        dma16(sel_ptr(b_ptr[j], zl, b_m[j] < me), lb);
-        b_ptr[j] += b_step;
+        buf_dma16(b_base, b_left, lb, b_off[j]);
       } else {
-        const int iy = xoy[j] * p.stride + kh - p.pad, ix0 = xox[j] * p.stride + kw0 - p.pad;
-        const bool rowok = ((unsigned)iy < (unsigned)p.Hi) && (b_m[j] < me);
-        const char* src0 = b_ptr[j] + ((long long)iy * p.Wi + ix0) * p.Ci * 2;   // never dereferenced when out of the image
+        const int iy = xoy[j] * p.stride + kh_p, ix0 = xox[j] * p.stride + kw_p;
+        const bool rowok = (unsigned)iy < (unsigned)p.Hi;
+        const unsigned off0 = b_off[j] + (unsigned)(iy * rowb + ix0 * pixb);     // garbage when the tap is padding: not used then
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const bool in = rowok && ((unsigned)(ix0 + t) < (unsigned)p.Wi);
-          dma16(sel_ptr(src0 + t * pixb, zl, in), lb + t * B_TILE);
+          buf_dma16(b_base, b_left, lb + t * B_TILE, in ? off0 + (unsigned)(t * pixb) : BUF_OOB);
         }
         if (fast_adv) {
           int ox = xox[j] + r64, oy = xoy[j] + q64;
@@ -669,18 +683,25 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
           oy = cx ? oy + 1 : oy;
           const bool cy = oy >= p.Ho;
           oy = cy ? oy - p.Ho : oy;
-          b_ptr[j] = cy ? b_ptr[j] + img : b_ptr[j];
+          b_off[j] = cy ? b_off[j] + imgb : b_off[j];
           xox[j] = ox; xoy[j] = oy;
         } else {
-          const int m = b_m[j] + BK;
-          const int n = m / hw;
-          const int rem = m - n * hw;
+          b_m[j] += BK;
+          const int n = b_m[j] / hw;
+          const int rem = b_m[j] - n * hw;
           xoy[j] = rem / p.Wo;
           xox[j] = rem - xoy[j] * p.Wo;
-          b_ptr[j] = Xb + (long long)n * img + b_cb;
+          b_off[j] = (unsigned)(n - n0) * imgb + b_chan;
         }
       }
-      b_m[j] += BK;
+    }
+    if constexpr (pc == NP - 1) {             // after the last piece of a K step: the linear descriptors move on (scalar unit)
+      a_base += a_stepb;
+      a_left = a_left > a_stepb ? a_left - a_stepb : 0;
+      if (p.simple_rows) {
+        b_base += b_stepb;
+        b_left = b_left > b_stepb ? b_left - b_stepb : 0;
+      }
     }
   };
 
@@ -971,8 +992,12 @@ int wgrad_bf16_pick_split(int M, int Co, int Ci, int T) {
   // the all-taps kernel runs one block per (tile, split) for all nine taps: 512 splits of the 64-channel layers fill the chip
   const int narrow_target = (T == 9 && wg16_halo()) ? 512 * 9 : 2560;
   int blocks_per_split = tiles > 0 ? tiles : 1;
-  if (wg16_rows(T == 9 ? 3 : 0, wide)) blocks_per_split = tiles / 3;     // `tiles` counts taps; a kernel-row block covers three
-  int split = (wide ? (tgt > 0 ? tgt : 1024) : narrow_target) / blocks_per_split;
+  int wide_target = 1024;
+  if (wg16_rows(T == 9 ? 3 : 0, wide)) {
+    blocks_per_split = tiles / 3;     // `tiles` counts taps; a kernel-row block covers three
+    wide_target = 512;                // exactly one round of the 2 blocks a CU holds (same box: 802 -> 835, 717 -> 750 TFLOP/s vs 1024)
+  }
+  int split = (wide ? (tgt > 0 ? tgt : wide_target) : narrow_target) / blocks_per_split;
   const int max_split = ceil_div(M, 256);
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
@@ -990,6 +1015,13 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   const double flops = 2.0 * (double)p.M * p.Co * (double)p.Ci * T;
   prof_begin(wide ? KC_WGRAD_WIDE : KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
   p.gx = tilesM * p.tilesN * T;
+  {   // buffer addressing: a block's operands are reached through 32-bit offsets from the first row / frame of its split
+    const long long lim = 0x7FFFF000LL;
+    const long long a_span = (long long)p.rows_per_split * p.Co * 2;
+    const long long frames = (long long)p.rows_per_split / ((long long)p.Ho * p.Wo) + 2;
+    const long long b_span = p.simple_rows ? (long long)p.rows_per_split * p.Ci * 2 : frames * p.Hi * p.Wi * p.Ci * 2;
+    R3M_REQUIRE(a_span < lim && b_span < lim, "wgrad(bf16): one split spans %lld / %lld bytes (limit 2 GiB): raise splitK (%d)", a_span, b_span, splitK);
+  }
   {
     const int il = R3M_ENV_INT("R3M_WG_INTERLEAVE", 0);
     p.interleave = il;
