@@ -93,25 +93,42 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   const int srow = lane / SPR, pslot = lane % SPR;
   auto swz = [](int r) __attribute__((always_inline)) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
   const int Hb = p.simple_rows ? 1 : p.Hi, Wb = p.simple_rows ? 1 : p.Wi;
+  // Round 3: both operands arrive through buffer descriptors (conv_dev.h buf_dma16; see wgrad_bf16_kernel for the measurement that
+  // motivated it: these kernels are instruction-issue-bound and the per-lane 64-bit source pointers were most of the vector work).
+  //   weights: constant per-lane offset; the (tap, K chunk) offset is wave-uniform and rides in the instruction's scalar offset;
+  //   activations: per-lane 32-bit offset relative to the frame of the tile's first row, recomputed only when the TAP changes
+  //     (padding -> out of range -> zeros); the K chunk inside the tap is the scalar offset again.
+  const long long imgA = (long long)p.Hi * p.Wi * p.Ci * 2;               // bytes per frame of A (simple rows: unused)
+  const int hwg = p.Hg * p.Wg;
+  const int nfirst = p.simple_rows ? 0 : (m0 < p.M ? m0 / hwg : 0);
+  const char* a_base = p.simple_rows ? Ab + (long long)m0 * p.Ci * 2 : Ab + (long long)nfirst * imgA;
+  int a_bytes;
+  {
+    const long long rest = p.simple_rows ? (long long)(p.M - m0) * p.Ci * 2 : (long long)(p.N - nfirst) * imgA;
+    a_bytes = rest <= 0 ? 0 : (rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB);
+  }
   RowDesc ad[AJ];
-  int acol[AJ];                        // byte offset inside the 128-byte K chunk this lane fetches (swizzled)
-  unsigned arow_ok = 0;
-  const char* bptr[BJ];
+  unsigned arel[AJ];                   // byte offset of the row's frame (simple rows: of the row) from a_base + swizzled slot, or BUF_OOB
+  unsigned avoff[AJ];                  // offset of the current tap's pixel (per lane), refreshed by set_tap
+  unsigned bvoff[BJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int r = wave * (BM / NW) + j * RPI + srow;
-    acol[j] = (pslot ^ swz(r)) * 16;
+    const unsigned col = (unsigned)((pslot ^ swz(r)) * 16);
     const int m = m0 + r;
     ad[j] = decode_row(p, m);
-    if (m < p.M) arow_ok |= 1u << j;
+    if (m >= p.M) arel[j] = BUF_OOB;
+    else if (p.simple_rows) arel[j] = (unsigned)(r * p.Ci * 2) + col;
+    else arel[j] = (unsigned)(m / hwg - nfirst) * (unsigned)imgA + col;
+    avoff[j] = arel[j];
   }
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int r = wave * (BN / NW) + j * RPI + srow;
     const int n = min(n0 + r, p.Nc - 1);                  // columns past Nc are computed on a clamped row, never stored
-    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ swz(r)) * 16;
+    bvoff[j] = (unsigned)(n * p.T * p.Ci * 2) + (unsigned)((pslot ^ swz(r)) * 16);
   }
-  const char* zline = reinterpret_cast<const char*>(g_zero_bytes) + pslot * 16;
+  const int b_bytes = p.Nc * p.T * p.Ci * 2;
 
   const int kpt = p.Ci / BK;          // K tiles per tap
   const int nk = p.ntaps * kpt;
@@ -120,12 +137,24 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
   int tap_n = 0, chunk_n = 0;
   int pack_cur = nk > 0 ? p.tap[0] : 0;
   int pack_next = p.ntaps > 1 ? p.tap[1] : pack_cur;
+  auto set_tap = [&](int pack) __attribute__((always_inline)) {
+    if (p.simple_rows) return;
+    const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
+      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && (arel[j] < BUF_OOB);
+      avoff[j] = in ? arel[j] + (unsigned)((iy * p.Wi + ix) * p.Ci * 2) : BUF_OOB;
+    }
+  };
+  if (nk > 0) set_tap(pack_cur);
   auto advance = [&]() __attribute__((always_inline)) {
     if (++chunk_n == kpt) {
       chunk_n = 0;
       ++tap_n;
       pack_cur = pack_next;
       pack_next = p.tap[min(tap_n + 1, p.ntaps - 1)];
+      set_tap(pack_cur);
     }
   };
   // one DMA piece of the cursor's tile into ring slot `stage`
@@ -136,18 +165,16 @@ void gather_gemm_bf16_kernel(const GatherGemmParams p) {
     unsigned char* lb = smem + stage * STAGE + BM * RB + wave * (BN / NW) * RB;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
-      const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
-      if ((R3M_PROBE(p) & 8) && dx != 0) return;     // probe 8: stage the A tile of the centre-column taps only (bytes-per-flop what-if)
-      if ((R3M_PROBE(p) & 16) && (dx != 0 || dy != 0)) return;   // probe 16: ... of the centre tap only
-      const int iy = ad[j].iy + dy, ix = ad[j].ix + dx;
-      const bool in = ((unsigned)iy < (unsigned)Hb) && ((unsigned)ix < (unsigned)Wb) && ((arow_ok >> j) & 1u);
-      const int iyc = min(max(iy, 0), Hb - 1), ixc = min(max(ix, 0), Wb - 1);
-      const char* src = Ab + (ad[j].base + ((long long)iyc * p.Wi + ixc) * p.Ci) * 2 + c0b + acol[j];
-      dma16(sel_ptr(src, zline, in), la + j * 1024);
+      if (R3M_PROBE(p) & 24) {
+        const int dy = (pack_cur << 24) >> 24, dx = (pack_cur << 16) >> 24;
+        if ((R3M_PROBE(p) & 8) && dx != 0) return;     // probe 8: stage the A tile of the centre-column taps only (bytes-per-flop what-if)
+        if ((R3M_PROBE(p) & 16) && (dx != 0 || dy != 0)) return;   // probe 16: ... of the centre tap only
+      }
+      buf_dma16(a_base, a_bytes, la + j * 1024, avoff[j], c0b);
     } else {
       constexpr int j = pc - AJ;
       const int wt = pack_cur >> 16;
-      dma16(bptr[j] + (long long)wt * p.Ci * 2 + c0b, lb + j * 1024);
+      buf_dma16(Bb, b_bytes, lb + j * 1024, bvoff[j], wt * p.Ci * 2 + c0b);
     }
   };
 
@@ -270,28 +297,37 @@ __global__ __launch_bounds__(256, BM / WM > 64 ? 2 : 1) void conv3x3_halo_bf16_k
 
   const int srow = lane >> 3, pslot = lane & 7;
   const long long hb = (long long)m0 - (W + 1);                        // pixel staged in halo row 0
-  const char* zline = reinterpret_cast<const char*>(g_zero_bytes) + pslot * 16;
+  // Round 3: buffer descriptors (see gather_gemm_bf16_kernel). Window rows: offsets relative to the first in-tensor pixel of the
+  // window, rows before the tensor get an out-of-range offset, rows past it fall off the descriptor; the 64-channel chunk is the
+  // scalar offset. Weights: constant per-lane offset, (tap, chunk) in the scalar offset.
+  const long long hb0 = hb > 0 ? hb : 0;
+  const char* a_base = Ab + hb0 * p.Ci * 2;
+  int a_bytes;
+  {
+    const long long rest = ((long long)p.M - hb0) * p.Ci * 2;
+    a_bytes = rest <= 0 ? 0 : (rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB);
+  }
+  const unsigned hcol = (unsigned)pslot;                               // physical slot; the logical one depends on the row
   // DMA instruction i of the window of chunk c: halo rows 8i .. 8i+7
   auto issue_halo = [&](int c, int i) __attribute__((always_inline)) {
     const int hr = 8 * i + srow;
     const long long px = hb + hr;
-    const bool in = px >= 0 && px < (long long)p.M;
-    const long long pc = in ? px : 0;
-    const char* src = Ab + (pc * p.Ci) * 2 + c * 128 + ((pslot ^ ((hr >> 1) & 7)) * 16);
-    dma16(sel_ptr(src, zline, in), smem + i * 1024);
+    const unsigned voff = px >= hb0 ? (unsigned)((int)(px - hb0) * p.Ci * 2) + ((hcol ^ (unsigned)((hr >> 1) & 7)) * 16u) : BUF_OOB;
+    buf_dma16(a_base, a_bytes, smem + i * 1024, voff, c * 128);
   };
-  const char* bptr[BJ];
+  unsigned bvoff[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int r = wave * (BN / 4) + j * 8 + srow;
     const int n = min(n0 + r, p.Nc - 1);
-    bptr[j] = Bb + ((long long)n * p.T * p.Ci) * 2 + (pslot ^ ((r >> 1) & 7)) * 16;
+    bvoff[j] = (unsigned)(n * p.T * p.Ci * 2) + (unsigned)((pslot ^ ((r >> 1) & 7)) * 16);
   }
+  const int b_bytes = p.Nc * p.T * p.Ci * 2;
   auto issue_w = [&](int c, int pack, int stage) __attribute__((always_inline)) {
     const int wt = pack >> 16;
     unsigned char* lb = wring + stage * WSTAGE + wave * (BN / 4) * 128;
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) dma16(bptr[j] + ((long long)wt * p.Ci) * 2 + c * 128, lb + j * 1024);
+    for (int j = 0; j < BJ; ++j) buf_dma16(Bb, b_bytes, lb + j * 1024, bvoff[j], wt * p.Ci * 2 + c * 128);
   };
 
   // per-lane rows of the two A row tiles: halo row of the centre tap and a 9-bit validity mask (bit = tap position in p.tap[])

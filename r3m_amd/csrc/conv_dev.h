@@ -477,10 +477,13 @@ constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count belo
 // One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
 // descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
 // builtin and would silently drop the kernels that call it).
-__device__ __forceinline__ void buf_dma16(const void* base, int bytes, void* lds, unsigned voff) {
+__device__ __forceinline__ void buf_dma16(const void* base, int bytes, void* lds, unsigned voff, int soff = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  // soff: wave-uniform byte offset added to the address (an SGPR operand of the instruction). Callers only put offsets there that
+  // keep a valid lane inside the tensor and an out-of-range lane out of range, so the result does not depend on whether the
+  // hardware includes it in the range check (tools/micro/bufload.hip: gfx950 does not)
   __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000 /* raw, 32-bit */),
-                                           (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+                                           (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 #endif
 }
 
