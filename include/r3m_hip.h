@@ -86,8 +86,6 @@ int r3m_conv2d_dgrad(const float* dy, const float* w_ohwi, float* dx, void* work
 size_t r3m_conv2d_wgrad_workspace_bytes(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
 int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw_ohwi, void* workspace, size_t workspace_bytes, int N, int Hi,
                      int Wi, int Ci, int Co, int k, int stride, int pad, int accumulate, r3m_stream_t stream);
-/* stem input transform: x/255 -> Normalize(mean,std) -> 7x7/2 p3 patches as rows of 160 floats (models_r3m.py:61,97-98) */
-int r3m_stem_im2col(const float* x_nchw, float* col, int frames, r3m_stream_t stream);
 /* the stem as the engine runs it (models_r3m.py:97-99 + torchvision conv1), no patch matrix in HBM:
  *   r3m_stem_prep      x [frames,3,224,224] fp32 NCHW in 0..255 -> xn [frames,224,224,3] = (x/255 - mean)/std (NHWC)
  *   r3m_stem_conv_fwd  xn, w_ohwi [64,7,7,3] -> y [frames,112,112,64] (NHWC) (+ BatchNorm partials [frames*49][2][64])

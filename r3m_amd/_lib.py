@@ -47,7 +47,6 @@ SIGNATURES = {
     "r3m_conv2d_dgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 8 + [c_f]),
     "r3m_conv2d_wgrad_workspace_bytes": (c_sz, [c_i] * 8),
     "r3m_conv2d_wgrad": (c_i, [c_f, c_f, c_f, c_f, c_sz] + [c_i] * 9 + [c_f]),
-    "r3m_stem_im2col": (c_i, [c_f, c_f, c_i, c_f]),
     "r3m_stem_prep": (c_i, [c_f, c_f, c_i, c_f]),
     "r3m_stem_conv_fwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_f]),
     "r3m_stem_conv_wgrad_workspace_bytes": (c_sz, []),

@@ -13,7 +13,7 @@
 
 // Traversal order of the streaming BatchNorm passes. The 256 MiB Infinity Cache still holds the TAIL of the tensor the previous
 // kernel streamed; a consumer that walks the rows in the opposite direction hits it first. R3M_BN_REV bit 1: forward apply, bit 2:
-// backward reduce, bit 4: backward apply walk from the last block down (compile-time; variants built by tools/experiments/build_probes.sh).
+// backward reduce, bit 4: backward apply walk from the last block down (compile-time; variants built by tools/build_ab.sh).
 #ifndef R3M_BN_REV
 #define R3M_BN_REV 0
 #endif

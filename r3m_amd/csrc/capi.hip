@@ -327,7 +327,6 @@ int r3m_conv2d_wgrad(const float* x, const float* dy, float* dw, void* ws, size_
                      int k, int stride, int pad, int accumulate, r3m_stream_t stream) {
   return r3m_conv2d_wgrad_dt(x, dy, dw, ws, ws_bytes, N, Hi, Wi, Ci, Co, k, stride, pad, accumulate, DT_F32, stream);
 }
-int r3m_stem_im2col(const float* x, float* col, int frames, r3m_stream_t stream) { return launch_stem_im2col(x, col, frames, S(stream)); }
 int r3m_stem_prep(const float* x, float* xn, int frames, r3m_stream_t stream) {
   R3M_REQUIRE(x && xn, "stem_prep: null argument");
   return launch_stem_prep(x, xn, frames, S(stream));

@@ -8,7 +8,7 @@
 // ---- experiment switches -------------------------------------------------------------------------------------
 // The SHIPPED library (r3m_amd/csrc/build.sh) has one code path per shape: it reads no environment variables and contains
 // none of the timing probes (some of which deliberately produce wrong results). Builds with -DR3M_PROBES
-// (tools/build_probes.sh) bring both back so the A/B measurements quoted in DESIGN.md can be repeated.
+// (tools/build_ab.sh none probes) bring both back so the A/B measurements quoted in DESIGN.md can be repeated.
 #ifdef R3M_PROBES
 #include <cstdlib>
 #define R3M_ENV_INT(name, dflt) ([]() -> int { static const int v_ = []() { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }(); return v_; }())
@@ -138,7 +138,6 @@ int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_pick_split(int M, int Co, int Ci, int T);
 int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s);
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
-int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s);
 int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s);
 struct FrameSource;   // augment_dev.h: raw clips + crop boxes
 int launch_stem_prep_crop(const FrameSource& src, float* xn, int F, hipStream_t s);
@@ -146,8 +145,6 @@ int launch_stem_prep16_crop(const FrameSource& src, void* xn16, int F, hipStream
 int launch_stem_fwd(const float* xn, const float* w147, void* y, float* stats, int F, int dt, hipStream_t s);
 size_t stem_wgrad_ws_floats();
 int launch_stem_wgrad(const float* xn, const void* dY, float* dw147, float* ws, int F, int accumulate, int dt, hipStream_t s);
-int launch_pack_stem_w(const float* w147, float* w160, hipStream_t s);
-int launch_unpack_stem_dw(const float* dw160, float* dw147, int accumulate, hipStream_t s);
 
 // ---- launchers (conv_bf16.hip) ----
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s);

@@ -756,8 +756,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   }
   for (int t = 0; t < p.ntaps; ++t)
     p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
-  // algorithmic FLOPs: the stem arrives as 160-wide patch rows of which 147 are real (7*7*3)
-  const double kdim = (double)p.ntaps * (p.Ci == 160 ? 147 : p.Ci);
+  const double kdim = (double)p.ntaps * p.Ci;
   const double flops = 2.0 * (double)p.M * (double)p.Nc * kdim;
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
@@ -774,14 +773,16 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
 #define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_GLDS2)
 #undef LAUNCH_GLDS2
-    } else if (gg_use_glds()) {
-#define LAUNCH_GLDS(E) hipLaunchKernelGGL((gather_gemm_glds_kernel<E>), dim3(grid), dim3(256), 0, s, p)
-      GG_EPI_SWITCH(LAUNCH_GLDS)
-#undef LAUNCH_GLDS
-    } else {
+#ifdef R3M_PROBES
+    } else if (!gg_use_glds()) {   // register-staged 128x128 kernel: A/B only (R3M_GG_GLDS=0)
 #define LAUNCH_REG(E) hipLaunchKernelGGL((gather_gemm_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_REG)
 #undef LAUNCH_REG
+#endif
+    } else {                       // odd Ci/32 (not a ResNet shape; reachable through r3m_conv2d_fwd / r3m_linear_fwd): generic direct-to-LDS kernel
+#define LAUNCH_GLDS(E) hipLaunchKernelGGL((gather_gemm_glds_kernel<E>), dim3(grid), dim3(256), 0, s, p)
+      GG_EPI_SWITCH(LAUNCH_GLDS)
+#undef LAUNCH_GLDS
     }
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
@@ -801,6 +802,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   return check_launch("gather_gemm");
 }
 
+#ifdef R3M_PROBES   // register-staged predecessor of wgrad_glds_kernel: kept for A/B in probe builds (R3M_WG_GLDS=0), not shipped
 // =====================================================================================================
 // wgrad: dW[co, tap, ci] = sum_m dY[m, co] * X[pix(m) + off(tap), ci].  GEMM M' = Co tile, N' = Ci tile,
 // K' = rows m (split over blockIdx.y). Both operands arrive row(m)-major with channels contiguous, which is exactly
@@ -970,6 +972,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       }
     }
 }
+
+#endif  // R3M_PROBES
 
 // =====================================================================================================
 // wgrad, direct-to-LDS staging through BUFFER addressing (round 3). Same GEMM as the register-staged probe kernel; the
@@ -1500,15 +1504,17 @@ int debug_occupancy(int* out4) {
   out4[1] = n;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gemm_glds2_kernel<256, 64, 4, 1, EPI_STATS>, 256, 0) != hipSuccess) return 1;
   out4[2] = n;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<128, 128>, 256, 0) != hipSuccess) return 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_glds_kernel<128, 128>, 256, 0) != hipSuccess) return 1;
   out4[3] = n;
   return 0;
 }
 
+#ifdef R3M_PROBES
 static bool wg_use_glds() {
   const int v = R3M_ENV_INT("R3M_WG_GLDS", 1) != 0;
   return v == 1;
 }
+#endif
 
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
 
@@ -1551,21 +1557,27 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     const int xc = R3M_ENV_INT("R3M_WG_XCD", 1);
     p.xcd = xc;
   }
-  const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * (p.Ci == 160 ? 147 : p.Ci);
+  const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * p.Ci;
   if (wg_wide(p.Co, p.Ci)) {
     p.tilesN = ceil_div(p.Ci, 128);
     const int tiles = ceil_div(p.Co, 128) * p.tilesN * T;
     prof_begin(KC_WGRAD_WIDE, flops, p.M, p.Co, p.Ci, T, s);
     p.gx = tiles;
-    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#ifdef R3M_PROBES
+    if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    else
+#endif
+    hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
     prof_begin(KC_WGRAD_NARROW, flops, p.M, p.Co, p.Ci, T, s);
     p.gx = tiles;
-    if (wg_use_glds()) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#ifdef R3M_PROBES
+    if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    else
+#endif
+    hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
   }
   prof_bytes(4.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci + (double)splitK * p.Co * T * p.Ci));
   prof_end(s);
@@ -1630,71 +1642,6 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s) {
   hipLaunchKernelGGL(transpose_w_kernel, dim3(ceil_div(Ci, 32), ceil_div(Co, 32), T), dim3(256), 0, s, W, Wt, Co, T, Ci);
   return check_launch("transpose_w");
-}
-
-// =====================================================================================================
-// Stem: the reference feeds [F,3,224,224] fp32 frames in 0..255 (NCHW) and does x/255 -> Normalize -> conv1 7x7/2 p3
-// (/root/reference/r3m/models/models_r3m.py:96-99). Zero padding happens AFTER normalisation, so the normalisation
-// cannot be folded into the weights. This kernel normalises and lays the 7x7x3 patches out as rows of 160 floats
-// (147 used, k = (kh*7 + kw)*3 + c, matching the OHWI weight image), which the gather-GEMM then consumes as a 1x1 conv.
-// =====================================================================================================
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int k4 = (int)(idx % 40);
-  const long long m = idx / 40;
-  const int ox = (int)(m % 112);
-  const long long t = m / 112;
-  const int oy = (int)(t % 112);
-  const long long f = t / 112;
-  const float mean[3] = {0.485f, 0.456f, 0.406f};
-  const float sd[3] = {0.229f, 0.224f, 0.225f};
-  f32x4 v;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int k = k4 * 4 + e;
-    float val = 0.f;
-    if (k < 147) {
-      const int tap = k / 3, c = k - tap * 3;
-      const int kh = tap / 7, kw = tap - kh * 7;
-      const int iy = oy * 2 + kh - 3, ix = ox * 2 + kw - 3;
-      if ((unsigned)iy < 224u && (unsigned)ix < 224u) {
-        const float px = x[((f * 3 + c) * 224 + iy) * 224 + ix];
-        val = (px / 255.0f - mean[c]) / sd[c];
-      }
-    }
-    v[e] = val;
-  }
-  *reinterpret_cast<f32x4*>(col + idx * 4) = v;
-}
-
-int launch_stem_im2col(const float* x_nchw, float* col, int F, hipStream_t s) {
-  const long long total = (long long)F * 112 * 112 * 40;
-  hipLaunchKernelGGL(stem_im2col_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, x_nchw, col, total);
-  return check_launch("stem_im2col");
-}
-
-__global__ void pack_stem_w_kernel(const float* __restrict__ w147, float* __restrict__ w160) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 64 * 160) return;
-  const int co = i / 160, k = i - co * 160;
-  w160[i] = (k < 147) ? w147[co * 147 + k] : 0.f;
-}
-int launch_pack_stem_w(const float* w147, float* w160, hipStream_t s) {
-  hipLaunchKernelGGL(pack_stem_w_kernel, dim3(40), dim3(256), 0, s, w147, w160);
-  return check_launch("pack_stem_w");
-}
-
-__global__ void unpack_stem_dw_kernel(const float* __restrict__ dw160, float* __restrict__ dw147, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 64 * 147) return;
-  const int co = i / 147, k = i - co * 147;
-  const float v = dw160[co * 160 + k];
-  dw147[i] = accumulate ? dw147[i] + v : v;
-}
-int launch_unpack_stem_dw(const float* dw160, float* dw147, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_stem_dw_kernel, dim3(ceil_div(64 * 147, 256)), dim3(256), 0, s, dw160, dw147, accumulate);
-  return check_launch("unpack_stem_dw");
 }
 
 }  // namespace r3m

@@ -527,7 +527,7 @@ static bool gg16_single() {
 // K tile width of a multi-tile launch. 32 (16 KB stages, THREE blocks per CU instead of two) wins where the epilogue is a large
 // part of a block's life — the expanding 1x1 convs and everything with a read-modify-write epilogue: -10..-33 % per launch on
 // ResNet-50 — because a third resident block covers it; 64 (half the barriers per K) wins by 3..16 % where the main loop
-// dominates: K >= 4 N, i.e. the 3x3 convs and the contracting 1x1 convs (per-shape table: tools/experiments/gpu_bk32b.sh).
+// dominates: K >= 4 N, i.e. the 3x3 convs and the contracting 1x1 convs (per-shape table measured in round 2: profiles/r02_*).
 // The 256x64 tile's 3x3 launches are the exception (measured -4 % with 32). R3M_BF16_BK=32 / 64 forces one width.
 static bool gg16_bk32(const GatherGemmParams& p, bool wide) {
   const int v = R3M_ENV_INT("R3M_BF16_BK", 0);

@@ -95,7 +95,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_shipped_library_reads_no_environment_switches():
     """SURVEY.md §8(b) / VERDICT r1 weak #11: experiment switches and the WRONG-result timing probes exist only in -DR3M_PROBES
-    builds (tools/experiments/build_probes.sh). The shipped .so carries none of their names and does not import getenv."""
+    builds (tools/build_ab.sh). The shipped .so carries none of their names and does not import getenv."""
     import subprocess
     from r3m_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()

@@ -67,7 +67,12 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
     # Gradient gate. fp32 round-off is amplified through 18-50 train-mode BatchNorm backward passes: the reference's OWN
     # PyTorch-CPU fp32 gradients sit 5e-3 (ResNet-18/34) to 2e-2 (ResNet-50) l2-rel away from a float64 evaluation of the
     # same graph at conv1 (tests/golden/encoder_r*_fp64.npz, printed by make_golden.py). So the HIP gradients are gated
-    # against float64 truth at <= 4x the reference-fp32 error of the same tensor (floor 1e-4; two independent fp32 evaluations differ by ~sqrt(2)x that error, and per-tensor ratios scatter up to ~3x), not fp32 against fp32.
+    # against float64 truth at <= 3x the reference-fp32 error of the same tensor (floor 1e-4), not fp32 against fp32. Measured
+    # ratios (profiles/r03_parity_report.txt): ResNet-18 1.0-1.6, ResNet-50 1.0-1.4, ResNet-34 2.1-2.6 on every early-layer tensor. The
+    # ResNet-34 figure is not scatter and not a reduction defect: the HIP forward decides ONE ReLU of the last block differently from
+    # float64 (z = +3.4e-5, the kink table below), which the reference's CPU evaluation happens not to; that one flipped element
+    # (1 of 200 704, ~2e-3 of |dz|) is carried down through 33 BatchNorm backward passes like any other fp32 perturbation and adds
+    # ~8e-3 to every early tensor (sqrt(9.4e-3^2 - 4.4e-3^2)); ResNet-18 / 50 have no flip that the reference does not share.
     g64 = np.load(os.path.join(golden_dir, f"encoder_r{size}_fp64.npz"))
     worst_hip = worst_cpu = 0.0
     for name, n32, n64 in zip(g["grad_names"], g["grad_norms"], g64["grad_norms"]):
@@ -75,7 +80,7 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
         worst_hip = max(worst_hip, abs(got - n64) / max(n64, 1e-12))
         worst_cpu = max(worst_cpu, abs(n32 - n64) / max(n64, 1e-12))
     report(f"r{size} grad-norm worst rel vs fp64: hip {worst_hip:.3e}  reference-cpu-fp32 {worst_cpu:.3e}")
-    assert worst_hip <= max(4.0 * worst_cpu, 1e-4)   # no blanket floor: the reference-fp32 error of the same tensors sets the scale
+    assert worst_hip <= max(3.0 * worst_cpu, 1e-4)   # no blanket floor: the reference-fp32 error of the same tensors sets the scale
     # Last BatchNorm: its gradients are gated UP TO ReLU decisions of the last block on elements whose float64 pre-activation lies
     # within 2e-4 of zero (tests/golden/encoder_r*_kink.npz). VERDICT r1 weak #3: ResNet-34's d(gamma) sat 1.3e-3 from float64
     # while the reference's CPU fp32 sat at 1e-6 — that is ONE element (z = +3.4e-5 in float64, decided <= 0 by the fp32 forward
@@ -109,7 +114,7 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
             hip_err = float(np.linalg.norm(r_g) / n_g)
         elif k == lb + ".bias":
             hip_err = float(np.linalg.norm(r_b) / n_b)
-        assert hip_err <= max(4.0 * cpu_err, 1e-4), k
+        assert hip_err <= max(3.0 * cpu_err, 1e-4), k
 
 
 @pytest.mark.parametrize("l2dist", [True, False])

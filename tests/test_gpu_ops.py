@@ -104,27 +104,6 @@ def test_conv_is_transpose_safe(hip):
     torch.testing.assert_close(nchw(yd.cpu()), y_ref, rtol=1e-6, atol=1e-5)
 
 
-def test_stem_im2col_conv(hip):
-    """x/255 -> Normalize -> conv 7x7/2 p3 (models_r3m.py:97-99) through the im2col + 160-wide GEMM route."""
-    Fr = 3
-    x = torch.floor(rnd((Fr, 3, 224, 224), 5, 0.0, 256.0)).clamp(0, 255)
-    w = rnd((64, 3, 7, 7), 6, -0.1, 0.1)
-    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
-    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    y_ref = F.conv2d((x / 255.0 - mean) / std, w, stride=2, padding=3)
-    col = torch.empty((Fr * 112 * 112, 160), device=DEV)
-    xd = x.to(DEV)
-    assert hip.r3m_stem_im2col(xd.data_ptr(), col.data_ptr(), Fr, st()) == 0
-    w160 = torch.zeros((64, 160))
-    w160[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
-    w160d = w160.to(DEV)
-    yd = torch.empty((Fr, 112, 112, 64), device=DEV)
-    rc = hip.r3m_conv2d_fwd(col.data_ptr(), w160d.data_ptr(), yd.data_ptr(), None, Fr * 112 * 112, 1, 1, 160, 64, 1, 1, 0, st())
-    assert rc == 0, hip.r3m_last_error()
-    e_max, _ = rel_err(nchw(yd.cpu()).numpy(), y_ref.numpy())
-    assert e_max < 2e-5
-
-
 @pytest.mark.parametrize("Fr", [1, 3])
 def test_stem_direct_fwd_wgrad(hip, Fr):
     """The engine's stem: /255 -> Normalize -> conv 7x7/2 p3 straight from NCHW frames, forward (+BN partials) and wgrad."""

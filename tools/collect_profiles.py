@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copy the summaries of the last tools/gpu_r2_final.sh run from gpurun_out/ (scratch) into profiles/ (tracked) under one tag:
+"""Copy the summaries of the last tools/gpu_evidence.sh run from gpurun_out/ (scratch) into profiles/ (tracked) under one tag:
 usage: collect_profiles.py r02_v1"""
 import os
 import shutil
