@@ -994,29 +994,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 //     SCALAR unit (in the shadow of the MFMAs); a padding row gets an out-of-range offset. Per lane: pick its row's scalar
 //     offset and add the channel offset = 3 (or 6) vector instructions per piece.
 // =====================================================================================================
-template <int BMt, int BNt>
-__global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
-  constexpr int BK = 32;
+// NT = 3 ("kernel rows", round 3): one block owns the THREE taps (kh, 0..2) of one row of a 3-wide kernel for its (co, ci) tile,
+// with three accumulator sets: the dY rows of a K step are staged and read from LDS ONCE for the three taps, the scalar cursor
+// walk is shared (the taps differ by one pixel in x) — 2/3 of the DMA instructions and fragment reads per MFMA of the per-tap
+// form. K steps of 16 rows keep the two stages at 64 KB (128-wide tile: 2 blocks per CU as before).
+template <int BMt, int BNt, int BK = 32, int NT = 1, int IL = -1>   // IL: DMA pieces spread between the MFMAs (1), in one burst (0), or p.interleave (-1)
+__global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_glds_kernel(const WgradParams p) {
+  static_assert(BK == 32 || BK == 16, "K step of 32 or 16 rows");
+  static_assert(NT == 1 || NT == 3, "one tap, or the three taps of a kernel row");
   // 128x128: waves 1 x 4, each 128 (co, interleaved: MFMA tile tm owns channels 4*i + tm) x 32 (ci) -> the A fragment of all
   // four tiles is ONE ds_read_b128 per K pair; 64x64: waves 2 x 2, each 32 x 32.
   constexpr bool WIDE = (BMt == 128);
   constexpr int TM = WIDE ? 4 : BMt / 64, TN = WIDE ? 1 : BNt / 64;
+  constexpr int WR = BK / 4;                            // k rows staged per wave per stage
   constexpr int A_RPI = 256 / BMt, B_RPI = 256 / BNt;   // k rows covered by one 1 KiB DMA instruction
-  constexpr int AJ = 8 / A_RPI, BJ = 8 / B_RPI;         // instructions per wave per stage (8 k rows per wave)
-  constexpr int STAGE = BK * (BMt + BNt);
+  constexpr int AJ = WR / A_RPI, BJ = WR / B_RPI;       // DMA pieces per wave per stage (a B piece = NT instructions)
+  static_assert(AJ >= 1 && BJ >= 1, "a wave stages whole DMA instructions");
+  constexpr int B_TILE = BK * BNt;                      // floats of one tap's X tile
+  constexpr int STAGE = BK * BMt + NT * B_TILE;
   __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WIDE ? 0 : (wave_s >> 1), wn = WIDE ? wave_s : (wave_s & 1);
   const int T = p.KH * p.KW;
+  const int TG = T / NT;                                // tap groups per tile (NT = 3: kernel rows)
   const int lid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int bx = lid % p.gx, by = lid / p.gx;   // by = split index: consecutive logical blocks read the same rows
-  const int tap = bx % T;
-  const int tile = bx / T;
+  const int tap0 = (bx % TG) * NT;
+  const int tile = bx / TG;
   const int tn_ = tile % p.tilesN, tm_ = tile / p.tilesN;
   const int co0 = tm_ * BMt, ci0 = tn_ * BNt;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int kh = tap0 / p.KW, kw0 = tap0 - kh * p.KW;
   const int ms = by * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
   const int hw = p.Ho * p.Wo;
@@ -1027,32 +1036,34 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   const unsigned a_chan = (co0 + a_c) < p.Co ? (unsigned)a_c * 4u : BUF_OOB;
   const unsigned b_chan = (ci0 + b_c) < p.Ci ? (unsigned)b_c * 4u : BUF_OOB;
 
-  // A operand (dY): descriptor = [row ms + 32*step, end of the split) x channels from co0
+  // A operand (dY): descriptor = [row ms + BK*step, end of the split) x channels from co0
   const float* a_base = p.dY + (long long)ms * p.Co + co0;
   int a_left = (int)(((long long)(me - ms) * p.Co - co0) * 4);      // bytes (host: a split spans < 2 GB)
-  const int a_stepb = 32 * p.Co * 4;
+  const int a_stepb = BK * p.Co * 4;
   unsigned a_voff[AJ];
 #pragma unroll
-  for (int j = 0; j < AJ; ++j) a_voff[j] = (unsigned)((wave_s * 8 + j * A_RPI + a_k) * p.Co) * 4u + a_chan;
+  for (int j = 0; j < AJ; ++j) a_voff[j] = (unsigned)((wave_s * WR + j * A_RPI + a_k) * p.Co) * 4u + a_chan;
 
   // B operand (X)
   const long long img = (long long)p.Hi * p.Wi * p.Ci;
   const float* b_base;
   int b_left;
-  const int b_stepb = 32 * p.Ci * 4;
+  const int b_stepb = BK * p.Ci * 4;
   unsigned b_voff[BJ];             // simple rows: constant per-lane offsets
-  // non-simple rows: ONE scalar cursor (frame offset, oy, ox) that walks the 8 consecutive rows this wave stages per K step,
-  // then jumps the 24 rows to its rows of the next step; `c_left` = rows from the cursor to the end of the split
+  // non-simple rows: ONE scalar cursor (frame offset, oy, ox) that walks the WR consecutive rows this wave stages per K step,
+  // then jumps the BK - WR rows to its rows of the next step; `c_left` = rows from the cursor to the end of the split
   int c_ox = 0, c_oy = 0, c_left = 0;
   unsigned c_f = 0;                // byte offset of the cursor row's frame from b_base
-  const int q24 = 24 / p.Wo, r24 = 24 - q24 * p.Wo;
+  constexpr int JUMP = BK - WR;
+  const int qj = JUMP / p.Wo, rj = JUMP - qj * p.Wo;
   const unsigned imgb = (unsigned)(img * 4);
-  const int kh_p = kh - p.pad, kw_p = kw - p.pad;
+  const int pixb = p.Ci * 4;       // bytes between the X rows of neighbouring taps (one pixel)
+  const int kh_p = kh - p.pad, kw_p = kw0 - p.pad;
   if (p.simple_rows) {
     b_base = p.X + (long long)ms * p.Ci + ci0;
     b_left = (int)(((long long)(me - ms) * p.Ci - ci0) * 4);
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) b_voff[j] = (unsigned)((wave_s * 8 + j * B_RPI + b_k) * p.Ci) * 4u + b_chan;
+    for (int j = 0; j < BJ; ++j) b_voff[j] = (unsigned)((wave_s * WR + j * B_RPI + b_k) * p.Ci) * 4u + b_chan;
   } else {
     const int n0 = ms / hw;        // first frame of the split: 32-bit offsets are relative to it
     b_base = p.X + (long long)n0 * img + ci0;
@@ -1060,7 +1071,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
     b_left = rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB;
 #pragma unroll
     for (int j = 0; j < BJ; ++j) b_voff[j] = 0;
-    const int m = ms + wave_s * 8;
+    const int m = ms + wave_s * WR;
     const int n = m / hw;
     const int rem = m - n * hw;
     c_oy = rem / p.Wo;
@@ -1072,26 +1083,28 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
 #pragma unroll
   for (int r = 0; r < B_RPI; ++r) b_is[r] = (b_k == r);
 
-  // one DMA piece (pc < AJ: dY rows, else X rows) into `stage`
+  // one DMA piece (pc < AJ: dY rows, else X rows of all NT taps) into `stage`
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
-      float* la = smem + stage * STAGE + wave_s * 8 * BMt;
+      float* la = smem + stage * STAGE + wave_s * WR * BMt;
       buf_dma16(a_base, a_left, la + j * A_RPI * BMt, a_voff[j]);
     } else {
       constexpr int j = pc - AJ;
-      float* lb = smem + stage * STAGE + BK * BMt + wave_s * 8 * BNt;
-      unsigned voff;
+      float* lb = smem + stage * STAGE + BK * BMt + wave_s * WR * BNt + j * B_RPI * BNt;
       if (p.simple_rows) {
-        voff = b_voff[j];
+        buf_dma16(b_base, b_left, lb, b_voff[j]);
       } else {
-        unsigned so[B_RPI];
+        unsigned so[NT][B_RPI];
 #pragma unroll
-        for (int r = 0; r < B_RPI; ++r) {     // scalar unit: tap shift, padding test, row offset, cursor to the next row
-          const int iy = c_oy * p.stride + kh_p, ix = c_ox * p.stride + kw_p;
-          const bool in = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (c_left > 0);
-          so[r] = in ? c_f + (unsigned)((iy * p.Wi + ix) * p.Ci) * 4u : BUF_OOB;
+        for (int r = 0; r < B_RPI; ++r) {     // scalar unit: tap shift, padding tests, row offset, cursor to the next row
+          const int iy = c_oy * p.stride + kh_p, ix0 = c_ox * p.stride + kw_p;
+          const bool rowok = ((unsigned)iy < (unsigned)p.Hi) && (c_left > 0);
+          const unsigned off0 = c_f + (unsigned)((iy * p.Wi + ix0) * p.Ci) * 4u;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            so[t][r] = (rowok && (unsigned)(ix0 + t) < (unsigned)p.Wi) ? off0 + (unsigned)(t * pixb) : BUF_OOB;
           c_left -= 1;
           c_ox += 1;
           if (c_ox == p.Wo) {
@@ -1100,27 +1113,29 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
             if (c_oy == p.Ho) { c_oy = 0; c_f += imgb; }
           }
         }
-        if constexpr (j == BJ - 1) {          // the wave's 8 rows of this K step are issued: jump to its rows of the next one
-          c_left -= 24;
-          c_ox += r24;
+        if constexpr (j == BJ - 1) {          // the wave's rows of this K step are issued: jump to its rows of the next one
+          c_left -= JUMP;
+          c_ox += rj;
           if (c_ox >= p.Wo) { c_ox -= p.Wo; c_oy += 1; }
-          c_oy += q24;
+          c_oy += qj;
           while (c_oy >= p.Ho) { c_oy -= p.Ho; c_f += imgb; }
         }
-        voff = so[0];
 #pragma unroll
-        for (int r = 1; r < B_RPI; ++r) voff = b_is[r] ? so[r] : voff;
-        voff += b_chan;
+        for (int t = 0; t < NT; ++t) {
+          unsigned voff = so[t][0];
+#pragma unroll
+          for (int r = 1; r < B_RPI; ++r) voff = b_is[r] ? so[t][r] : voff;
+          buf_dma16(b_base, b_left, lb + t * B_TILE, voff + b_chan);
+        }
       }
-      buf_dma16(b_base, b_left, lb + j * B_RPI * BNt, voff);
     }
   };
-  // after the last piece of a K step: both descriptors move on by 32 rows (scalar)
+  // after the last piece of a K step: both descriptors move on by BK rows (scalar)
   auto advance = [&]() __attribute__((always_inline)) {
-    a_base += 32 * p.Co;
+    a_base += BK * p.Co;
     a_left = a_left > a_stepb ? a_left - a_stepb : 0;
     if (p.simple_rows) {
-      b_base += 32 * p.Ci;
+      b_base += BK * p.Ci;
       b_left = b_left > b_stepb ? b_left - b_stepb : 0;
     }
   };
@@ -1129,25 +1144,28 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
     advance();
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[NT][TM][TN];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
 
   const int lrow = lane & 31, lh = lane >> 5;
   const float* fragA = smem + lh * BMt + (WIDE ? 4 * lrow : wm * TM * 32 + lrow);
   const float* fragB = smem + BK * BMt + lh * BNt + wn * TN * 32 + lrow;
-  // MFMAs of one stage; when dma_stage >= 0 the next K step's DMA pieces are spread between them (one piece per
-  // 16/(AJ+BJ) K pairs) so that their issue cost hides behind this wave's own MFMAs
+  // MFMAs of one stage; when dma_stage >= 0 the next K step's DMA pieces are spread between them so that their issue cost
+  // hides behind this wave's own MFMAs
   auto mfma_stage = [&](const float* fa, const float* fb, int dma_stage) __attribute__((always_inline)) {
     constexpr int NP = AJ + BJ;
-    constexpr int EVERY = (BK / 2) / NP;     // K pairs between two pieces: 2 (128x128: 8 pieces) or 4 (64x64: 4 pieces)
+    constexpr int EVERY = (BK / 2) / NP;     // K pairs between two pieces
+    static_assert(EVERY >= 1, "at most one DMA piece per K pair");
     static_for<BK / 2>([&](auto kk_c) __attribute__((always_inline)) {
       constexpr int kk = decltype(kk_c)::value;
-      float a[TM], b[TN];
+      float a[TM];
       if constexpr (WIDE) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(fa + kk * 2 * BMt);
 #pragma unroll
@@ -1157,13 +1175,17 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
         for (int t = 0; t < TM; ++t) a[t] = fa[kk * 2 * BMt + t * 32];
       }
 #pragma unroll
-      for (int t = 0; t < TN; ++t) b[t] = fb[kk * 2 * BNt + t * 32];
+      for (int tp = 0; tp < NT; ++tp) {
+        float b[TN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+        for (int t = 0; t < TN; ++t) b[t] = fb[tp * B_TILE + kk * 2 * BNt + t * 32];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-      if constexpr ((kk % EVERY) == EVERY - 1) {
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tp][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tp][tm][tn], 0, 0, 0);
+      }
+      if constexpr ((kk % EVERY) == EVERY - 1 && kk / EVERY < NP) {
         if (dma_stage >= 0) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(dma_stage, std::integral_constant<int, kk / EVERY>{});
@@ -1177,10 +1199,11 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
   const int nk = (me - ms + BK - 1) / BK;
   if (nk > 0) issue(0);
   int kt = 0;
+  const bool il = IL < 0 ? (p.interleave != 0) : (IL != 0);
   for (; kt + 1 < nk; kt += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.interleave) {
+    if (il) {
       mfma_stage(fragA, fragB, 1);
     } else {
       issue(1);
@@ -1188,7 +1211,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.interleave) {
+    if (il) {
       mfma_stage(fragA + STAGE, fragB + STAGE, (kt + 2 < nk) ? 0 : -1);
     } else {
       if (kt + 2 < nk) issue(0);
@@ -1203,18 +1226,20 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
 
   float* out = p.out + (long long)by * p.Co * T * p.Ci;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int co = WIDE ? co0 + 4 * rho + tm : co0 + (wm * TM + tm) * 32 + rho;
-      if (co >= p.Co) continue;
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
-        if (ci < p.Ci) out[((long long)co * T + tap) * p.Ci + ci] = acc[tm][tn][r];
+      for (int r = 0; r < 16; ++r) {
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = WIDE ? co0 + 4 * rho + tm : co0 + (wm * TM + tm) * 32 + rho;
+        if (co >= p.Co) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int ci = ci0 + (wn * TN + tn) * 32 + lrow;
+          if (ci < p.Ci) out[((long long)co * T + tap0 + tp) * p.Ci + ci] = acc[tp][tm][tn][r];
+        }
       }
-    }
 }
 
 // =====================================================================================================
@@ -1517,13 +1542,19 @@ static bool wg_use_glds() {
 #endif
 
 static inline bool wg_wide(int Co, int Ci) { return (Co % 128 == 0) && (Ci % 128 == 0); }
+// 3-wide kernels run one block per kernel row (wgrad_glds_kernel NT = 3). R3M_WG_ROWS=0 (probe builds): per-tap blocks.
+static bool wg_rows(int KW) {
+  const int v = R3M_ENV_INT("R3M_WG_ROWS", 1);
+  return v && KW == 3;
+}
 
 // Split-K factor: enough blocks for two full waves of resident blocks (128x128: 2 blocks/CU x 256 CUs; 64x64: 5/CU), as few
 // splits as that allows (every split writes and re-reads a full dW slab), never fewer than 8 K steps per block.
 int wgrad_pick_split(int M, int Co, int Ci, int T) {
   const bool wide = wg_wide(Co, Ci);
   const int bt = wide ? 128 : 64;
-  const long long tiles = (long long)ceil_div(Co, bt) * ceil_div(Ci, bt) * T;
+  long long tiles = (long long)ceil_div(Co, bt) * ceil_div(Ci, bt) * T;
+  if (T == 9 && wg_rows(3)) tiles /= 3;     // kernel-row blocks cover three taps each
   const long long target = wide ? 1024 : 2560;
   long long split = target / tiles;   // floor: never spill a few blocks into an extra wave
   const long long max_split = (M + 255) / 256;
@@ -1567,6 +1598,10 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
     else
 #endif
+    if (wg_rows(p.KW)) {   // 3-wide kernels: one block per kernel row (three taps), K steps of 16 rows
+      p.gx = ceil_div(p.Co, 128) * p.tilesN * p.KH;
+      hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 16, 3, 1>), dim3(p.gx * splitK), dim3(256), 0, s, p);
+    } else
     hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
@@ -1577,6 +1612,10 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
     else
 #endif
+    if (wg_rows(p.KW)) {
+      p.gx = ceil_div(p.Co, 64) * p.tilesN * p.KH;
+      hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 16, 3, 0>), dim3(p.gx * splitK), dim3(256), 0, s, p);
+    } else
     hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
   }
   prof_bytes(4.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci + (double)splitK * p.Co * T * p.Ci));
