@@ -1555,7 +1555,8 @@ int wgrad_pick_split(int M, int Co, int Ci, int T) {
   const int bt = wide ? 128 : 64;
   long long tiles = (long long)ceil_div(Co, bt) * ceil_div(Ci, bt) * T;
   if (T == 9 && wg_rows(3)) tiles /= 3;     // kernel-row blocks cover three taps each
-  const long long target = wide ? 1024 : 2560;
+  const int tgt = R3M_ENV_INT("R3M_WG_BLOCKS", 0);                       // probe builds: block target override
+  const long long target = tgt > 0 ? tgt : (wide ? 1024 : 2560);
   long long split = target / tiles;   // floor: never spill a few blocks into an extra wave
   const long long max_split = (M + 255) / 256;
   if (split > max_split) split = max_split;
