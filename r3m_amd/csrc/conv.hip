@@ -690,6 +690,207 @@ __global__ __launch_bounds__(WM * WN * 64) void gather_gemm_kernel(const GatherG
   gg_epilogue<BM, BN, WM, WN, EPI, STAGE>(p, acc, smem, m0, n0, mt);
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolutions (forward and dgrad) on 128-wide outputs with an INPUT WINDOW in LDS (round 3).
+// The gather kernel stages the 128-row A tile once per tap: 4 of its 8 DMA instructions per 64 MFMAs, and on this chip DMA issue
+// is what keeps the fp32 main loop at 0.83 instead of the 0.9+ of a no-load loop (the weight gradient gained 6 % from 8 -> 5.3
+// DMA instructions per 64 MFMAs). Here the nine taps of a tile of 128 consecutive output pixels read ONE window of 128 + 2W + 2
+// input pixels per 32-channel chunk — staged once per chunk, double-buffered, one DMA instruction per tap step — plus the nine
+// weight tiles: 4.7 DMA instructions per 64 MFMAs.
+//   LDS (80 KB, two blocks per CU): 2 window buffers of 192 rows x 128 B (same 16-byte-slot XOR swizzle as the gather kernel),
+//   2 weight stages of 128 x 128 B. Window row 191 is never inside the window (W <= 28): its DMA lanes are out of range, it holds
+//   zeros, and a lane whose pixel has no (y + dy, x + dx) inside the image reads IT — the gather kernel's border arithmetic.
+//   The A-fragment addresses of all 9 taps x 2 row tiles x 4 K groups are per-lane constants (72 registers), so the K loop has no
+//   vector work: DMA offsets are constants, the (tap, chunk) position rides in the instructions' scalar offset.
+// Summation order: (chunk, tap) instead of the gather kernel's (tap, chunk) — an fp32 reassociation, inside every gate.
+// =====================================================================================================
+// In use: <128,128,2,2,192> (W <= 28: the 128/256/512-channel layers; 80 KB, two blocks of 4 waves per CU): 126 -> 131, 133 -> 140,
+// 133 -> 141 TFLOP/s at 14^2 / 28^2 / 7^2 (profiles/r03_win_ab.txt). The template also instantiates as <256,64,4,2,376> (the
+// 64-channel layers at 56 x 56: 112 KB, ONE block of 8 waves per CU); measured 122 against the gather kernel's 124 there
+// (a 370-row window per 2 chunks of 9 taps amortises less, and one block per CU exposes the chunk boundary) — not dispatched.
+template <int BM, int BN, int WIN_ROWS>
+struct WinCfg {
+  static constexpr int WIN_BYTES = WIN_ROWS * 128;
+  static constexpr int LDS = 2 * WIN_BYTES + 2 * BN * 128;
+};
+
+template <int BM, int BN, int WM, int WN, int WIN_ROWS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv3x3_win_kernel(const GatherGemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM == 2 && (TN == 1 || TN == 2), "wave tile 64 x 32 or 64 x 64");
+  constexpr int WIN_BYTES = WIN_ROWS * 128;
+  constexpr int BSTAGE = BN * 128;                               // bytes of one weight stage
+  constexpr int LDSB = 2 * WIN_BYTES + 2 * BSTAGE;
+  extern __shared__ __attribute__((aligned(128))) unsigned char wsm[];
+  unsigned char* bst = wsm + 2 * WIN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s / WN, wn = wave_s % WN;
+  const int gridN = (p.Nc + BN - 1) / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / gridN, nt = lid % gridN;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int W = p.Wi, H = p.Hi, HW = H * W;
+  const int HR = BM + 2 * W + 2;                                 // window rows in use (< WIN_ROWS)
+  constexpr int ZR = WIN_ROWS - 1;                               // the zero row
+
+  // ---- A fragment byte offsets inside a window buffer: [tap][row tile][K group] ----
+  const int lrow = lane & 31, lh = lane >> 5;
+  unsigned fa[9][TM][4];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * (BM / WM) + t * 32 + lrow;
+    const int m = m0 + r;
+    int y = 0, x = 0;
+    if (m < p.M) {
+      const int rem = m % HW;
+      y = rem / W;
+      x = rem - y * W;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int pk = p.tap[k];
+      const int dy = (pk << 24) >> 24, dx = (pk << 16) >> 24;
+      const bool ok = (m < p.M) && ((unsigned)(y + dy) < (unsigned)H) && ((unsigned)(x + dx) < (unsigned)W);
+      const unsigned wr = ok ? (unsigned)(r + (W + 1) + dy * W + dx) : (unsigned)ZR;
+      const unsigned base = (wr << 7) | (((wr >> 1) & 7u) << 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fa[k][t][g] = base ^ ((unsigned)(2 * g + lh) << 4);
+    }
+  }
+  // ---- B fragment byte offsets inside a weight stage ----
+  unsigned fb[4];
+  {
+    const int xr = (lrow >> 1) & 7;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fb[g] = (unsigned)((wn * TN * 32 + lrow) * 128 + (((2 * g + lh) ^ xr) << 4));
+  }
+
+  // ---- DMA: window pieces (8 rows each; this wave owns pieces wave_s + NW q) and weight pieces (8 rows each) ----
+  const int srow = lane >> 3, pslot = lane & 7;
+  const long long px00 = (long long)m0 - (W + 1);                // pixel of window row 0
+  const long long pxb = px00 > 0 ? px00 : 0;                     // descriptor base pixel
+  const float* a_base = p.A + pxb * p.Ci;
+  int a_bytes;
+  {
+    const long long rest = ((long long)p.M - pxb) * p.Ci * 4;
+    a_bytes = rest <= 0 ? 0 : (rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB);
+  }
+  constexpr int NWP_ALL = WIN_ROWS / 8;                          // window pieces of a full buffer
+  constexpr int NWQ = (NWP_ALL + NW - 1) / NW;                   // per wave (6)
+  static_assert(NWQ <= 9, "one window piece per tap step");
+  unsigned woff[NWQ];
+#pragma unroll
+  for (int q = 0; q < NWQ; ++q) {
+    const int hr = 8 * (wave_s + NW * q) + srow;
+    const long long px = px00 + hr;
+    const bool ok = hr < HR && px >= 0;                          // px >= M falls off the descriptor
+    woff[q] = ok ? (unsigned)((int)(px - pxb) * p.Ci * 4) + (unsigned)((pslot ^ ((hr >> 1) & 7)) << 4) : BUF_OOB;
+  }
+  const int nwp = (HR + 7) / 8;                                  // pieces that hold window rows; the last piece (zero row) always goes
+  constexpr int BJ = BN / 8 / NW;                                // weight pieces per wave (4 or 1)
+  static_assert(BJ >= 1 && BJ * 8 * NW == BN, "weight rows split over the waves");
+  unsigned bvoff[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int r = wave_s * (BN / NW) + j * 8 + srow;
+    const int n = min(n0 + r, p.Nc - 1);
+    bvoff[j] = (unsigned)(n * p.T * p.Ci * 4) + (unsigned)((pslot ^ ((r >> 1) & 7)) << 4);
+  }
+  const int b_bytes = p.Nc * p.T * p.Ci * 4;
+
+  auto issue_window_piece = [&](int q, int chunk, int buf) __attribute__((always_inline)) {
+    const int i = wave_s + NW * q;
+    if (i < nwp || i == NWP_ALL - 1)
+      buf_dma16(a_base, a_bytes, wsm + buf * WIN_BYTES + i * 1024, woff[q], chunk * 128);
+  };
+  auto issue_b_piece = [&](int j, int tapk, int chunk, int stage) __attribute__((always_inline)) {
+    const int wt = p.tap[tapk] >> 16;
+    buf_dma16(p.B, b_bytes, bst + stage * BSTAGE + (wave_s * (BN / NW) + j * 8) * 128, bvoff[j], (wt * p.Ci + chunk * 32) * 4);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = p.Ci >> 5;
+  // one tap step: the MFMAs of window buffer WB (tap K) x weight stage ST, carrying the DMA of the NEXT step's weights and one
+  // window piece of the next chunk
+  auto step = [&](auto k_c, auto wb_c, auto st_c, int chunk) __attribute__((always_inline)) {
+    constexpr int K = decltype(k_c)::value, WB = decltype(wb_c)::value, ST = decltype(st_c)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool last_chunk = chunk + 1 >= nchunks;
+    const bool more_b = !(last_chunk && K == 8);
+    const int nk = K == 8 ? 0 : K + 1, nc = K == 8 ? chunk + 1 : chunk;
+    static_for<4>([&](auto g_c) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_c)::value;
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        a[t] = *reinterpret_cast<const f32x4*>(wsm + WB * WIN_BYTES + fa[K][t][g]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        b[t] = *reinterpret_cast<const f32x4*>(bst + ST * BSTAGE + t * 32 * 128 + fb[g]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+        if (j == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (g < BJ && more_b) issue_b_piece(g, nk, nc, ST ^ 1);
+          if (g == 3 && K < NWQ && !last_chunk) issue_window_piece(K, chunk + 1, WB ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    });
+  };
+  auto chunk_steps = [&](auto wb_c, int chunk) __attribute__((always_inline)) {
+    constexpr int WB = decltype(wb_c)::value;                  // window buffer = chunk parity; weight stage = (chunk + tap) parity
+    static_for<9>([&](auto k_c) __attribute__((always_inline)) {
+      constexpr int K = decltype(k_c)::value;
+      step(k_c, wb_c, std::integral_constant<int, (WB + K) & 1>{}, chunk);
+    });
+  };
+
+  if (nchunks > 0) {
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) issue_window_piece(q, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) issue_b_piece(j, 0, 0, 0);
+  }
+  int c = 0;
+  for (; c + 1 < nchunks; c += 2) {
+    chunk_steps(std::integral_constant<int, 0>{}, c);
+    chunk_steps(std::integral_constant<int, 1>{}, c + 1);
+  }
+  if (c < nchunks) chunk_steps(std::integral_constant<int, 0>{}, c);
+  __syncthreads();
+
+  gg_epilogue<BM, BN, WM, WN, EPI, LDSB / 4>(p, acc, reinterpret_cast<float*>(wsm), m0, n0, mt);
+}
+
+// 3x3 / stride 1 / pad 1 on the full pixel grid with the taps being exactly {-1,0,1}^2, 128-wide outputs, W <= 28
+static bool conv3x3_win_eligible(const GatherGemmParams& p, int maxW) {
+  if (p.ntaps != 9 || p.is != 1 || p.os != 1 || p.simple_rows || p.Hg != p.Hi || p.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi) return false;
+  if (p.Wi > maxW || p.Wi < 1 || (p.Ci & 31)) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (p.dy[t] < -1 || p.dy[t] > 1 || p.dx[t] < -1 || p.dx[t] > 1) return false;
+    seen |= 1u << ((p.dy[t] + 1) * 3 + (p.dx[t] + 1));
+  }
+  return seen == 0x1ffu && (long long)p.Nc * p.T * p.Ci * 4 < 0x7FFFF000LL;
+}
+
 static inline bool gg_wide(int Nc) { return (Nc % 128) == 0; }
 
 int gather_gemm_grid_m(int M, int Nc) { return gg_wide(Nc) ? ceil_div(M, 128) : ceil_div(M, 256); }
@@ -763,6 +964,23 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
     // short main loop + wide output: single tap, K <= 256, N >= 2 K (expanding / downsample 1x1 convolutions) -> 16-wide K tiles
     // R3M_GG_K16 (probe builds): 0 = never, 1 = the rule above, 2 = every wide launch (experiment: 4 blocks per CU everywhere)
+    {
+      const int winmode = R3M_ENV_INT("R3M_GG_WIN", 1);           // probe builds: 0 = gather kernel for 3x3 / stride 1 too
+      if (winmode && conv3x3_win_eligible(p, 28)) {
+        typedef WinCfg<128, 128, 192> Cfg;
+#define LAUNCH_WIN(E)                                                                                                        \
+  do {                                                                                                                       \
+    static DynLdsOptIn oi;                                                                                                   \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(conv3x3_win_kernel<128, 128, 2, 2, 192, E>), Cfg::LDS, "conv3x3_win")) return e; \
+    hipLaunchKernelGGL((conv3x3_win_kernel<128, 128, 2, 2, 192, E>), dim3(grid), dim3(256), Cfg::LDS, s, p);                 \
+  } while (0)
+        GG_EPI_SWITCH(LAUNCH_WIN)
+#undef LAUNCH_WIN
+        prof_bytes(gather_gemm_alg_bytes(p, 4));
+        prof_end(s);
+        return check_launch("conv3x3_win");
+      }
+    }
     const int k16_mode = R3M_ENV_INT("R3M_GG_K16", 1);
     const bool short_loop = (p.Ci & 31) == 0 && (k16_mode == 2 || (k16_mode == 1 && p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci));
     if (short_loop) {
