@@ -36,6 +36,47 @@ def _last_bn(size):
     return "layer4.2.bn3" if size == 50 else ("layer4.1.bn2" if size == 18 else "layer4.2.bn2")
 
 
+def _float64_grads_with_decisions(size, flip_idx, keys):
+    """Float64 oracle gradients of the G1 case with the last block's ReLU decided as the HIP forward decided it at the listed
+    elements (flat NCHW index into the block's pre-ReLU sum, float64_was_on): on -> forced off (output 0, no gradient), off ->
+    forced on (pass-through). Runs on the GPU box's CPU (seconds)."""
+    from oracle import detgen, r3m_ref
+    ref = r3m_ref.R3MRef(size=size, langweight=0.0, tcnweight=1.0)
+    shapes = [(k, tuple(v.shape)) for k, v in ref.convnet.state_dict().items()]
+    ref.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes, "w").items()})
+    ref = ref.double()
+    ref.train()
+    net = ref.convnet
+    blk = net.layer4[-1]
+    off = torch.tensor([i for i, was_on in flip_idx if was_on], dtype=torch.long)
+    on = torch.tensor([i for i, was_on in flip_idx if not was_on], dtype=torch.long)
+
+    class Forced(torch.nn.Module):
+        def __init__(self, nth):
+            super().__init__()
+            self.nth, self.k = nth, 0
+
+        def forward(self, z):
+            self.k += 1
+            y = torch.relu(z)
+            if self.k == self.nth:                         # the block's LAST ReLU (after the residual add)
+                flat_z, flat_y = z.flatten(), y.flatten().clone()
+                if len(on):
+                    flat_y[on] = flat_z[on]
+                if len(off):
+                    flat_y[off] = 0.0
+                y = flat_y.view_as(z)
+            return y
+
+    blk.relu = Forced(3 if size == 50 else 2)
+    x = torch.from_numpy(detgen.frames("frames8", (8, 3, 224, 224))).double()
+    h = net(ref.normlayer(x / 255.0))
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).double()
+    (h * cw).sum().backward()
+    P = dict(net.named_parameters())
+    return {k: P[k].grad.numpy() for k in keys}
+
+
 @pytest.mark.parametrize("size", [18, 34, 50])
 def test_encoder_matches_reference_golden(hip, golden_dir, size):
     from oracle import detgen
@@ -90,13 +131,14 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
     kink = np.load(os.path.join(golden_dir, f"encoder_r{size}_kink.npz"))
     r_b = P[lb + ".bias"].grad.cpu().double().numpy() - g64["grad_" + lb + ".bias"].astype(np.float64)
     r_g = P[lb + ".weight"].grad.cpu().double().numpy() - g64["grad_" + lb + ".weight"].astype(np.float64)
-    flips = []
-    for c, z, dgam, dbet in zip(kink["channel"], kink["z"], kink["dgamma"], kink["dbeta"]):
+    flips, flip_idx = [], []
+    for c, z, dgam, dbet, fi in zip(kink["channel"], kink["z"], kink["dgamma"], kink["dbeta"], kink["idx"]):
         sgn = -1.0 if z > 0 else 1.0                       # float64 had it on (off): deciding otherwise removes (adds) its term
         if abs(r_b[c] - sgn * dbet) < 0.25 * abs(dbet):    # the channel's d(beta) residual IS this element's dz
             r_b[c] -= sgn * dbet
             r_g[c] -= sgn * dgam
             flips.append((int(c), float(z)))
+            flip_idx.append((int(fi), bool(z > 0)))
     n_b = float(np.linalg.norm(g64["grad_" + lb + ".bias"].astype(np.float64)))
     n_g = float(np.linalg.norm(g64["grad_" + lb + ".weight"].astype(np.float64)))
     report(f"r{size} last BatchNorm: {len(flips)} ReLU decision(s) differ from float64 at |z| < {float(kink['tau']):.0e}: {flips}; "
@@ -106,6 +148,14 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
     assert len(flips) <= max(3, len(kink["z"]) // 4)
     keys = ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",
             "layer2.0.downsample.0.weight")
+    # A flipped decision of the LAST block is not confined to the last BatchNorm: the element's dz (1 of 200 704, ~2e-3 of |dz|)
+    # travels down through every BatchNorm backward like any other perturbation and reaches conv1 amplified — measured on
+    # ResNet-34: one flip -> conv1.weight 2.1x the reference-fp32 error, two flips (round 3, after an fp32 reassociation in the
+    # 3x3 kernels moved z[37] = -1.1e-4 across zero as well) -> 3.3x. So when a tensor misses the 3x gate and flips were
+    # identified, the float64 oracle is evaluated HERE, on this box's CPU, with exactly those decisions imposed
+    # (_float64_grads_with_decisions), and the gate is applied against THAT: the HIP gradients must equal the float64 gradients
+    # of the network that makes the same ReLU decisions, to 3x the reference's own fp32 error.
+    forced = None
     for k in keys:
         hip_err = rel_err(P[k].grad.cpu().numpy(), g64["grad_" + k])[1]
         cpu_err = rel_err(g["grad_" + k], g64["grad_" + k])[1]
@@ -114,6 +164,11 @@ def test_encoder_matches_reference_golden(hip, golden_dir, size):
             hip_err = float(np.linalg.norm(r_g) / n_g)
         elif k == lb + ".bias":
             hip_err = float(np.linalg.norm(r_b) / n_b)
+        if hip_err > max(3.0 * cpu_err, 1e-4) and flip_idx and k not in (lb + ".weight", lb + ".bias"):
+            if forced is None:
+                forced = _float64_grads_with_decisions(size, flip_idx, keys)
+            hip_err = rel_err(P[k].grad.cpu().numpy(), forced[k])[1]
+            report(f"r{size} grad {k}: l2-rel vs fp64 WITH the {len(flip_idx)} identified ReLU decision(s) imposed: hip {hip_err:.3e}")
         assert hip_err <= max(3.0 * cpu_err, 1e-4), k
 
 
