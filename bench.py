@@ -393,6 +393,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The GPU step needs ONE host thread (plus autograd's); torch's intra-op pool defaults to a thread per core (256 here), and
+    # its wake-ups next to the launching thread cost up to +85 ms per 94 ms step of the launch-dense ResNet-34 bf16 workload
+    # (measured round 3). cpu_baseline() sets its own thread count afterwards.
+    torch.set_num_threads(4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the

@@ -27,27 +27,31 @@ def _fallback_box(height, width, ratio):
 
 
 def sample_boxes(n, height, width, scale=(0.2, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), generator=None):
-    """[n,4] int32 (top, left, h, w) for n boxes in a handful of tensor ops (host RNG, torch CPU generator): torchvision's
+    """[n,4] int32 (top, left, h, w) for n boxes in a handful of array ops (host RNG, torch CPU generator): torchvision's
     RandomResizedCrop.get_params algorithm — up to 10 tries of area ~ U(scale) * A with a log-uniform aspect ratio, the first
     try that fits wins and gets a uniform position, else the centre fallback — evaluated for all boxes and tries at once
-    (round 1 looped in Python with 2-4 scalar RNG calls per box: 6.5 % of the ResNet-34 bf16 step at 512 clips)."""
+    (round 1 looped in Python with 2-4 scalar RNG calls per box: 6.5 % of the ResNet-34 bf16 step at 512 clips).
+    The arithmetic runs in numpy on purpose: ~20 torch CPU ops per step woke torch's intra-op thread pool (one thread per core of
+    a 256-thread host) next to the thread that launches the kernels — measured +7 ... +85 ms per 94 ms step when this ran after
+    other workloads in the same process (bench.py's secondary configs[4]; 93.2 ms with torch.set_num_threads(1))."""
+    import numpy as np
     area = float(height * width)
-    ua, ur, ui, uj = _box_randoms(n, generator)
+    ua, ur, ui, uj = (t.numpy() for t in _box_randoms(n, generator))
     target = area * (scale[0] + (scale[1] - scale[0]) * ua)
-    ar = torch.exp(math.log(ratio[0]) + (math.log(ratio[1]) - math.log(ratio[0])) * ur)
-    w = torch.round(torch.sqrt(target * ar)).to(torch.int64)
-    h = torch.round(torch.sqrt(target / ar)).to(torch.int64)
+    ar = np.exp(math.log(ratio[0]) + (math.log(ratio[1]) - math.log(ratio[0])) * ur)
+    w = np.round(np.sqrt(target * ar)).astype(np.int64)
+    h = np.round(np.sqrt(target / ar)).astype(np.int64)
     ok = (w > 0) & (w <= width) & (h > 0) & (h <= height)
-    first = torch.argmax(ok.to(torch.int8), dim=1)                 # first try that fits (0 when none does: masked below)
-    any_ok = ok.any(dim=1)
-    rows = torch.arange(n)
+    first = np.argmax(ok, axis=1)                                   # first try that fits (0 when none does: masked below)
+    any_ok = ok.any(axis=1)
+    rows = np.arange(n)
     hh, ww = h[rows, first], w[rows, first]
-    top = torch.floor(ui * (height - hh + 1).to(torch.float64)).to(torch.int64).clamp_(max=height - 1)
-    left = torch.floor(uj * (width - ww + 1).to(torch.float64)).to(torch.int64).clamp_(max=width - 1)
-    out = torch.stack([top, left, hh, ww], dim=1)
-    fb = torch.tensor(_fallback_box(height, width, ratio), dtype=torch.int64)
-    out = torch.where(any_ok[:, None], out, fb[None, :])
-    return out.to(torch.int32)
+    top = np.minimum(np.floor(ui * (height - hh + 1).astype(np.float64)).astype(np.int64), height - 1)
+    left = np.minimum(np.floor(uj * (width - ww + 1).astype(np.float64)).astype(np.int64), width - 1)
+    out = np.stack([top, left, hh, ww], axis=1)
+    fb = np.asarray(_fallback_box(height, width, ratio), dtype=np.int64)
+    out = np.where(any_ok[:, None], out, fb[None, :])
+    return torch.from_numpy(out.astype(np.int32))
 
 
 def _sample_boxes_scalar(n, height, width, scale=(0.2, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), generator=None):

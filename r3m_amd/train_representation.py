@@ -46,6 +46,9 @@ class Workspace:
         self.work_dir = Path(work_dir or Path.cwd())
         self.cfg = cfg
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        # The training process's own torch CPU work is a few tiny tensors per step (permutations, crop boxes); a thread per core
+        # of intra-op pool next to the kernel-launching thread only costs (measured: up to +85 ms per 94 ms ResNet-34 bf16 step).
+        torch.set_num_threads(min(torch.get_num_threads(), 8))
         utils.set_seed_everywhere(cfg.seed + self.rank)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.logger = Logger(self.work_dir / f"logs_rank{self.rank}", use_tb=False, cfg=cfg if self.rank == 0 else None)
