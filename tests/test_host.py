@@ -237,3 +237,16 @@ def test_optimizer_state_of_another_owner_set_is_refused():
     old = {"step": 4, "exp_avg": [None], "exp_avg_sq": [None], "param_groups": sd1["param_groups"]}   # round-1 layout: one shared step
     enc_only.encoder_opt.load_state_dict(old)
     assert enc_only.encoder_opt._steps == [4]
+
+
+def test_box_sampler_matches_the_scalar_get_params_loop():
+    """The vectorised (numpy) RandomResizedCrop box sampler picks, from the SAME per-try random numbers, the boxes torchvision's
+    get_params loop (restated scalar form) picks — /root/reference/r3m/utils/data_loaders.py:47-50 uses scale=(0.2, 1.0)."""
+    from r3m_amd import augment
+    for n, H, W in ((257, 256, 256), (64, 224, 300), (9, 8, 1000), (5, 1000, 8)):
+        g1, g2 = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+        a = augment.sample_boxes(n, H, W, generator=g1)
+        b = augment._sample_boxes_scalar(n, H, W, generator=g2)
+        assert a.dtype == torch.int32 and tuple(a.shape) == (n, 4) and torch.equal(a, b), (n, H, W)
+        top, left, h, w = a.unbind(1)
+        assert (top >= 0).all() and (left >= 0).all() and (top + h <= H).all() and (left + w <= W).all()
