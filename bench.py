@@ -99,6 +99,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=8)
     ap.add_argument("--launch-csv", default="", help="write one row per conv GEMM launch of the timed steps (layer report)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend; nccl (= RCCL) is the product path, gloo exists so that the N > 1 code of this script "
+                         "(rank launch, barriers, max-over-ranks timing, secondary workloads on every rank) can run on a ONE-GPU box")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="with --backend gloo: rank r uses GPU r %% visible GPUs (all ranks on one device of a one-GPU box)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="re-launch under torch.distributed.run also for --gpus 1 (the self-spawn path on a one-GPU box; N > 1 always does)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -143,9 +148,9 @@ def launch_plan(args, environ, argv, port=None):
             os.path.abspath(__file__)] + list(argv)
 
 
-def self_spawn(cmd, n):
+def self_spawn(cmd, n, share_gpu=False):
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not share_gpu:
         raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
@@ -275,7 +280,8 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_max, dt_min, comm_exposed_ms = float(t[0].item()), -float(t[1].item()), float(t[2].item())
         dt = dt_max
-    collectives = (f"rccl all_reduce(AVG), {net.sync.launched / max(1, total_steps):.1f} per step"
+    collectives = ((f"rccl all_reduce(AVG)" if dist.is_initialized() and dist.get_backend() == "nccl" else "gloo all_reduce(SUM)/N")
+                   + f", {net.sync.launched / max(1, total_steps):.1f} per step"
                    + (" (one-rank group: identity, issued to exercise the path)" if world == 1 else "")) if use_dist \
         else "none (single process)"
 
@@ -321,7 +327,8 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
                          "kernels": kernels},
         }
         if use_dist:
-            out["rccl_ranks"] = dist.get_world_size()
+            out["rccl_ranks"] = dist.get_world_size()                  # ranks of the process group (RCCL unless "backend" says gloo)
+            out["backend"] = dist.get_backend()
             out["ms_per_step_rank_min"] = round(dt_min / steps * 1e3, 3)
             out["ms_per_step_rank_max"] = round(dt_max / steps * 1e3, 3)
             out["comm_exposed_ms"] = round(comm_exposed_ms, 4)     # per step, max over ranks: compute stream idle in work.wait()
@@ -388,7 +395,7 @@ def main():
     args = parse_args()
     cmd = launch_plan(args, os.environ, sys.argv[1:])
     if cmd is not None:
-        raise SystemExit(self_spawn(cmd, args.gpus))
+        raise SystemExit(self_spawn(cmd, args.gpus, args.share_gpu))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -397,15 +404,21 @@ def main():
     # its wake-ups next to the launching thread cost up to +85 ms per 94 ms step of the launch-dense ResNet-34 bf16 workload
     # (measured round 3). cpu_baseline() sets its own thread count afterwards.
     torch.set_num_threads(4)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.share_gpu and args.backend != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the
     # gradient all-reduces are issued — also with one rank, where a mean over one rank is the identity: `torchrun
     # --nproc-per-node 1 bench.py --gpus 1` therefore executes the same collective / barrier / max-over-ranks code that N = 8 runs.
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist}
 
     w = dict(size=args.size, clips=args.clips_per_gpu, precision=args.precision, langweight=args.langweight, doaug=args.doaug,

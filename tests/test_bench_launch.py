@@ -85,3 +85,12 @@ def test_pmc_summary_is_only_used_for_its_own_workload_and_kernel():
         assert t is None and "not this workload" in src
         t, src = bench.pmc_traffic(bf16, w["size"], w["clips"], bench.KCLASS[3])
         assert t is None and "dominant class here" in src
+
+
+def test_gloo_share_gpu_flags_reach_the_ranks():
+    argv = ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2"]
+    a = _args(*argv)
+    assert a.backend == "gloo" and a.share_gpu
+    cmd = bench.launch_plan(a, {}, argv, port=7)
+    assert cmd[-len(argv):] == argv and "--nproc-per-node=2" in cmd
+    assert _args().backend == "nccl" and not _args().share_gpu
