@@ -1657,17 +1657,59 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) tot[t][r] = 0.f;
 
-  for (int row = blockIdx.x; row < total_rows; row += gridDim.x) {
+  // Round 3: register prefetch. The next output row's operands (7 input rows = 1176 float4, the dY row = 1792 float4: 5 + 7 per
+  // thread) are requested BEFORE this row's MFMAs and written to LDS after them, so their global latency (~2 us of the ~6.5 us a
+  // row took) rides under the matrix work instead of in front of it. The zero borders of the patch rows never change: written once.
+  constexpr int PQ = (7 * 168 + 255) / 256, DQ = 112 * 16 / 256;     // 5, 7
+  f32x4 pre_p[PQ], pre_d[DQ];
+  auto request = [&](int row) __attribute__((always_inline)) {
+    const long long f = row / 112;
+    const int iy0 = 2 * (row - (int)f * 112) - 3;
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+      const int i = tid + 256 * k;
+      const int y = i / 168, q = i - y * 168;
+      const int iy = iy0 + y;
+      pre_p[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 7 * 168 && (unsigned)iy < 224u) pre_p[k] = ldg4(x + ((f * 224 + iy) * 224) * 3 + q * 4);
+    }
+    const T* src = dY + (long long)row * 112 * 64;
+#pragma unroll
+    for (int k = 0; k < DQ; ++k) pre_d[k] = ld4t(src + (tid + 256 * k) * 4);
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+      const int i = tid + 256 * k;
+      if (i < 7 * 168) {
+        const int y = i / 168, q = i - y * 168;
+        float* d = patch + y * ST_PSW + 9 + q * 4;     // 9-float left border: not 16-byte aligned -> scalar LDS stores
+        d[0] = pre_p[k][0]; d[1] = pre_p[k][1]; d[2] = pre_p[k][2]; d[3] = pre_p[k][3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DQ; ++k) *reinterpret_cast<f32x4*>(dys + (tid + 256 * k) * 4) = pre_d[k];
+  };
+  {
+    constexpr int TAIL = ST_PSW - 681;
+    for (int i = tid; i < 7 * (9 + TAIL); i += 256) {
+      const int y = i / (9 + TAIL), e = i - y * (9 + TAIL);
+      patch[y * ST_PSW + (e < 9 ? e : 672 + e)] = 0.f;
+    }
+  }
+  int row = blockIdx.x;
+  if (row < total_rows) {
+    request(row);
+    commit();
+  }
+  __syncthreads();
+  for (; row < total_rows; row += gridDim.x) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const long long f = row / 112;
-    const int oy = row - (int)f * 112;
-    stem_load_patch<ST_PSW>(x, patch, f, 2 * oy - 3, 7);
-    const T* src = dY + (long long)row * 112 * 64;
-    for (int i = tid; i < 112 * 16; i += 256) *reinterpret_cast<f32x4*>(dys + i * 4) = ld4t(src + i * 4);
-    __syncthreads();
+    const int next = row + gridDim.x;
+    if (next < total_rows) request(next);
     if (wj == 0) {
 #pragma unroll
       for (int q = 0; q < 56; ++q) {
@@ -1687,6 +1729,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) tot[t] += acc[t];
+    __syncthreads();                      // every wave is done reading this row's tiles
+    if (next < total_rows) commit();
     __syncthreads();
   }
   float* out = partial + (long long)blockIdx.x * 64 * 160;
