@@ -1565,12 +1565,48 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 #pragma unroll
   for (int t = 0; t < 2; ++t) b_base[t] = (t * 32 + lrow) * ST_KS + lh;
 
+  // Round 3: register prefetch — the 13 input rows of the NEXT tile (2184 float4, 9 per thread) are requested before this tile's
+  // MFMAs and written to LDS after its epilogue (whose slabs alias the patch), so their latency rides under the matrix work.
+  constexpr int PQ = (13 * 168 + 255) / 256;
+  f32x4 pre[PQ];
+  auto request = [&](int blk) __attribute__((always_inline)) {
+    const long long f = blk / 49;
+    const int iy0 = 2 * (((blk - (int)f * 49) * 256) / 112) - 3;
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+      const int i = tid + 256 * k;
+      const int y = i / 168, q = i - y * 168;
+      const int iy = iy0 + y;
+      pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 13 * 168 && (unsigned)iy < 224u) pre[k] = ldg4(xn + ((f * 224 + iy) * 224) * 3 + q * 4);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+    for (int i = tid; i < 13 * 20; i += 256) {       // zero borders: the epilogue's slabs overwrote them
+      const int y = i / 20, e = i - y * 20;
+      patch[y * ST_PS + (e < 9 ? e : 672 + e)] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+      const int i = tid + 256 * k;
+      if (i < 13 * 168) {
+        const int y = i / 168, q = i - y * 168;
+        float* d = patch + y * ST_PS + 9 + q * 4;     // 9-float left border: not 16-byte aligned -> scalar LDS stores
+        d[0] = pre[k][0]; d[1] = pre[k][1]; d[2] = pre[k][2]; d[3] = pre[k][3];
+      }
+    }
+  };
+  if ((int)blockIdx.x < ntiles) {
+    request(blockIdx.x);
+    commit();
+  }
   for (int blk = blockIdx.x; blk < ntiles; blk += gridDim.x) {
     const long long f = blk / 49;
     const int lm0 = (blk - (int)f * 49) * 256;    // first output pixel of this tile inside its frame (12544 = 49 * 256)
     const int oy0 = lm0 / 112;
-    stem_load_patch(xn, patch, f, 2 * oy0 - 3, 13);
-    __syncthreads();
+    __syncthreads();                              // the patch of this tile (and, first time, the weights) is in LDS
+    const int nblk = blk + gridDim.x;
+    if (nblk < ntiles) request(nblk);
     int a_base[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1602,7 +1638,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
       }
     __syncthreads();
     gg_epilogue<256, 64, 4, 1, EPI, 13 * ST_PS, OT>(p, acc, smem, blk * 256, 0, blk);
-    __syncthreads();   // the epilogue slabs alias the patch that the next iteration refills
+    __syncthreads();   // the epilogue slabs alias the patch that is refilled now
+    if (nblk < ntiles) commit();
   }
 }
 
