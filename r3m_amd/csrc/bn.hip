@@ -844,10 +844,110 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
   else *reinterpret_cast<uint2*>(amax + idx * V) = make_uint2(bi[0], bi[1]);
 }
 
+// bf16 form of the fused forward. The activated values are >= 0 and rounded to bf16, so as fp32 bit patterns they order like
+// integers and their low 16 bits are free: key = bits(z) | (15 - code) turns "first maximum in scan order" into ONE integer max per
+// candidate (largest value, then smallest window code), instead of a compare and two selects. A thread owns (px, 8 channels) and walks
+// POOL_SEG consecutive output rows downwards: the horizontal 3-tap maxima of input row 2*py+1 are carried into window py+1 (whose
+// row 2*(py+1)-1 it is) with the code's row part re-based by plain subtraction (the low bits never borrow: 15 - 3i - j >= 7), so an
+// output costs two new input rows, not three. Measured against the one-output-per-thread kernel above: see DESIGN.md §4.2.
+constexpr int POOL_SEG = 8;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct Keys8 { int k[8]; };
+
+__device__ __forceinline__ void pool_tap_keys(const bf16_t* __restrict__ p, const f32x8& sc, const f32x8& sh, int kc, Keys8& h) {
+  const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float ylo = __builtin_bit_cast(float, raw[q] << 16), yhi = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
+    const float slo = q < 2 ? sc.lo[2 * q] : sc.hi[2 * q - 4], shi = q < 2 ? sc.lo[2 * q + 1] : sc.hi[2 * q - 3];
+    const float tlo = q < 2 ? sh.lo[2 * q] : sh.hi[2 * q - 4], thi = q < 2 ? sh.lo[2 * q + 1] : sh.hi[2 * q - 3];
+    f32x2 z;
+    z[0] = fmaxf(fmaf(ylo, slo, tlo), 0.f);
+    z[1] = fmaxf(fmaf(yhi, shi, thi), 0.f);
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(z, bf16x2));   // one v_cvt_pk_bf16_f32
+    const int klo = (int)((u << 16) | (unsigned)kc), khi = (int)((u & 0xffff0000u) | (unsigned)kc);
+    h.k[2 * q] = h.k[2 * q] > klo ? h.k[2 * q] : klo;
+    h.k[2 * q + 1] = h.k[2 * q + 1] > khi ? h.k[2 * q + 1] : khi;
+  }
+}
+
+// horizontal maxima (keys with the column part of the code) of input row y at columns 2*px-1 .. 2*px+1
+__device__ __forceinline__ void pool_row_keys(const bf16_t* __restrict__ Yrow, int px, int Wi, int CV, int cv, const f32x8& sc,
+                                              const f32x8& sh, Keys8& h) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h.k[e] = 0;
+  const bf16_t* p = Yrow + ((long long)(2 * px) * CV + cv) * 8;
+  if (px > 0) pool_tap_keys(p - (long long)CV * 8, sc, sh, 15, h);
+  pool_tap_keys(p, sc, sh, 14, h);
+  if (2 * px + 1 < Wi) pool_tap_keys(p + (long long)CV * 8, sc, sh, 13, h);
+}
+
+__global__ __launch_bounds__(1024) void bn_relu_maxpool_fwd16_kernel(const bf16_t* __restrict__ Y, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, bf16_t* __restrict__ P,
+                                                                     unsigned char* __restrict__ amax, int Hi, int Wi, int Ho, int Wo,
+                                                                     int CV, int cv_log2, int segs) {
+  const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+  const int py0 = seg * POOL_SEG;
+  const int py1 = py0 + POOL_SEG < Ho ? py0 + POOL_SEG : Ho;
+  const int items = Wo * CV;
+  const bf16_t* Yn = Y + (long long)n * Hi * Wi * CV * 8;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int px = it >> cv_log2, cv = it & (CV - 1);
+    const f32x8 sc = ld8f(scale + cv * 8), sh = ld8f(shift + cv * 8);
+    Keys8 hp, ha, hb;
+    if (py0 > 0) pool_row_keys(Yn + (long long)(2 * py0 - 1) * Wi * CV * 8, px, Wi, CV, cv, sc, sh, hp);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hp.k[e] = 0;
+    }
+    for (int py = py0; py < py1; ++py) {
+      pool_row_keys(Yn + (long long)(2 * py) * Wi * CV * 8, px, Wi, CV, cv, sc, sh, ha);
+      if (2 * py + 1 < Hi) pool_row_keys(Yn + (long long)(2 * py + 1) * Wi * CV * 8, px, Wi, CV, cv, sc, sh, hb);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hb.k[e] = 0;
+      }
+      u32x4 val;
+      unsigned code[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int b[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int e = 2 * q + r;
+          int m = ha.k[e] - 3;                       // window row 1; an absent row (key 0) goes negative and loses
+          m = hp.k[e] > m ? hp.k[e] : m;             // window row 0
+          const int m2 = hb.k[e] - 6;                // window row 2
+          b[r] = m > m2 ? m : m2;
+          hp.k[e] = hb.k[e];
+        }
+        val[q] = ((unsigned)b[0] >> 16) | ((unsigned)b[1] & 0xffff0000u);
+        const unsigned c2 = ((unsigned)b[0] & 15u) | (((unsigned)b[1] & 15u) << 8);
+        if ((q & 1) == 0) code[q >> 1] = c2; else code[q >> 1] |= c2 << 16;
+      }
+      const long long o = ((((long long)n * Ho + py) * Wo + px) * CV + cv) * 8;
+      *reinterpret_cast<u32x4*>(P + o) = val;
+      *reinterpret_cast<uint2*>(amax + o) = make_uint2(0x0f0f0f0fu - code[0], 0x0f0f0f0fu - code[1]);
+    }
+  }
+}
+
+static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// threads of a block that owns Wo x CV (pixel, channel-vector) items: all of them when they fit, else 1024 (a multiple of CV <= 256)
+static inline int pool_row_threads(int items) { return items >= 1024 ? 1024 : (items + 63) / 64 * 64; }
+
 int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
                                int Wi, int C, int dt, hipStream_t s) {
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
   R3M_REQUIRE(C % 8 == 0, "bn_relu_maxpool_fwd: C=%d must be a multiple of 8", C);
+  if (dt == DT_BF16 && is_pow2(C) && C <= 2048) {
+    const int CV = C / 8, segs = ceil_div(Ho, POOL_SEG);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd16_kernel, dim3(N * segs), dim3(pool_row_threads(Wo * CV)), 0, s,
+                       static_cast<const bf16_t*>(Y), scale, shift, static_cast<bf16_t*>(P), amax, Hi, Wi, Ho, Wo, CV, ilog2_exact(CV), segs);
+    return check_launch("bn_relu_maxpool_fwd16");
+  }
   DT_DISPATCH(dt, "bn_relu_maxpool_fwd", {
     constexpr int V = 4 * PoolVec<T>::V4;
     const long long total = (long long)N * Ho * Wo * (C / V);
@@ -857,91 +957,131 @@ int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* s
   return check_launch("bn_relu_maxpool_fwd");
 }
 
-// gradient w.r.t. the (never stored) pre-pool activation at pixel (n, y, x), channel vector cv
+// Backward through the (never stored) pre-pool activation, quad form. Windows of 3x3 / stride 2 / pad 1 tile the image into 2x2
+// quads: quad (qy, qx) = pixels (2qy + a, 2qx + b), a, b in {0, 1}, lies inside its HOME window (qy, qx) (codes 4, 5, 7, 8); its right
+// column is also column 0 of window (qy, qx+1) (codes 3, 6), its lower row is row 0 of window (qy+1, qx) (codes 1, 2), and pixel
+// (1, 1) is code 0 of window (qy+1, qx+1). One thread = one quad x V channels: four window reads (pooled gradient + argmax bytes,
+// the home one coalesced with the pooled tensor's own layout) serve four pixels, all twelve loads are issued before the first use,
+// and there is no data-dependent loop. (The per-pixel gather it replaces read 2.25 windows per pixel in a divergent loop with a
+// wait per window: 2.2-3.0 TB/s; rounds of dependent L2 hits, not bytes, were the bound.) Per pixel the contributions are added
+// in window scan order, as the stand-alone maxpool_bwd_kernel does, and rounded to the storage type as the stored dZ0 was.
 template <class T>
-__device__ __forceinline__ void pool_gradv(const T* __restrict__ dP, const unsigned char* __restrict__ amax, long long n, int y, int x,
-                                           int cv, int Ho, int Wo, int CV, f32x4 (&g)[PoolVec<T>::V4]) {
+struct PoolQuad {
+  static constexpr int V4 = PoolVec<T>::V4;
+  f32x4 y[4][V4];      // pixel (a, b) at [2a + b]
+  f32x4 dz[4][V4];
+  bool va, vb;         // row 2qy+1 / column 2qx+1 exist
+};
+
+template <class T>
+__device__ __forceinline__ void pool_quad(const T* __restrict__ dP, const unsigned char* __restrict__ amax, const T* __restrict__ Y,
+                                          long long n, int qy, int qx, int cv, int Hi, int Wi, int Ho, int Wo, int CV, PoolQuad<T>& q) {
   constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
+  const bool hr = qx + 1 < Wo, hd = qy + 1 < Ho;
+  q.va = 2 * qy + 1 < Hi;
+  q.vb = 2 * qx + 1 < Wi;
+  const long long o = (((n * Ho + qy) * Wo + qx) * CV + cv) * V;
+  const long long sW = (long long)CV * V, sH = (long long)Wo * CV * V;
+  const long long oo[4] = {o, hr ? o + sW : o, hd ? o + sH : o, (hr && hd) ? o + sH + sW : o};
+  const long long p = (((n * Hi + 2 * qy) * Wi + 2 * qx) * CV + cv) * V;
+  const long long pH = (long long)Wi * CV * V;
+  const long long pp[4] = {p, q.vb ? p + sW : p, q.va ? p + pH : p, (q.va && q.vb) ? p + pH + sW : p};
+  unsigned a[4][V4];
+  f32x4 d[4][V4];
 #pragma unroll
-  for (int k = 0; k < V4; ++k) g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int py0 = y >> 1, py1 = (y + 1) >> 1;   // windows py with 2*py-1 <= y <= 2*py+1
-  const int px0 = x >> 1, px1 = (x + 1) >> 1;
-  for (int py = py0; py <= py1; ++py) {
-    if (py >= Ho) continue;
-    const int i = y - (py * 2 - 1);
-    for (int px = px0; px <= px1; ++px) {
-      if (px >= Wo) continue;
-      const int j = x - (px * 2 - 1);
-      const unsigned code = (unsigned)(i * 3 + j);
-      const long long o = (((n * Ho + py) * Wo + px) * CV + cv) * V;
-      unsigned a[V4];
-      f32x4 d[V4];
-      ld_codes<V4>(amax + o, a);
-      ldv<V4>(dP + o, d);
+  for (int w = 0; w < 4; ++w) ldv_stream<V4>(Y + pp[w], q.y[w]);
 #pragma unroll
-      for (int k = 0; k < V4; ++k)
+  for (int w = 0; w < 4; ++w) { ld_codes<V4>(amax + oo[w], a[w]); ldv<V4>(dP + oo[w], d[w]); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (((a[k] >> (8 * e)) & 0xffu) == code) g[k][e] += d[k][e];
-    }
+  for (int k = 0; k < V4; ++k) {            // a window that does not exist matches no code
+    if (!hr) { a[1][k] = 0xffffffffu; a[3][k] = 0xffffffffu; }
+    if (!hd) { a[2][k] = 0xffffffffu; a[3][k] = 0xffffffffu; }
   }
 #pragma unroll
-  for (int k = 0; k < V4; ++k) g[k] = round_as<T>(g[k]);
+  for (int k = 0; k < V4; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned cH = (a[0][k] >> (8 * e)) & 0xffu, cR = (a[1][k] >> (8 * e)) & 0xffu;
+      const unsigned cD = (a[2][k] >> (8 * e)) & 0xffu, cX = (a[3][k] >> (8 * e)) & 0xffu;
+      const float dH = d[0][k][e], dR = d[1][k][e], dD = d[2][k][e], dX = d[3][k][e];
+      q.dz[0][k][e] = cH == 4u ? dH : 0.f;
+      q.dz[1][k][e] = (cH == 5u ? dH : 0.f) + (cR == 3u ? dR : 0.f);
+      q.dz[2][k][e] = (cH == 7u ? dH : 0.f) + (cD == 1u ? dD : 0.f);
+      q.dz[3][k][e] = (((cH == 8u ? dH : 0.f) + (cR == 6u ? dR : 0.f)) + (cD == 2u ? dD : 0.f)) + (cX == 0u ? dX : 0.f);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) q.dz[w][k] = round_as<T>(q.dz[w][k]);
+  }
 }
 
-// pass 1 of BatchNorm backward with dZ gathered through the max-pool: same work split as bn_bwd_reduce_kernel
+// pass 1 of BatchNorm backward with dZ gathered through the max-pool. A block owns `rq` consecutive quad rows (n, qy) and all
+// Wo x CV (quad, channel-vector) items of a row; a thread's channel vector is loop-invariant, its sums stay in registers, and
+// the block's threads of one channel vector are combined in a fixed order (two LDS stages) into one partial row.
 template <class T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
-                                                                  const T* __restrict__ Y, const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                  const float* __restrict__ invstd, float* __restrict__ partials,
-                                                                  long long rows, int C, int cpb, int rows_per_block, int Hi, int Wi,
-                                                                  int Ho, int Wo) {
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                                   const T* __restrict__ Y, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float* __restrict__ partials,
+                                                                   int quad_rows, int rq, int C, int CV, int cv_log2, int Hi, int Wi,
+                                                                   int Ho, int Wo) {
   constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
-  __shared__ f32x4 red[2][V4][256];
-  const int tcol = threadIdx.x % cpb, trow = threadIdx.x / cpb;
-  const int rpp = 256 / cpb;
-  const int cv = blockIdx.y * cpb + tcol;
+  extern __shared__ f32x4 pool_red[];            // [2][V4][blockDim.x]
+  const int nt = blockDim.x;
+  const int cv = threadIdx.x & (CV - 1);
   const int c = cv * V;
-  const long long r_begin = (long long)blockIdx.x * rows_per_block;
-  long long r_end = r_begin + rows_per_block;
-  if (r_end > rows) r_end = rows;
+  const int items = Wo * CV;
   f32x4 sc[V4], sh[V4], mu[V4], is[V4], s1[V4], s2[V4];
 #pragma unroll
   for (int k = 0; k < V4; ++k) {
     sc[k] = ld4(scale + c + 4 * k); sh[k] = ld4(shift + c + 4 * k); mu[k] = ld4(mean + c + 4 * k); is[k] = ld4(invstd + c + 4 * k);
     s1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // (n, y, x) of the thread's first pixel once; then advanced by rpp pixels per iteration (no divisions in the loop)
-  long long r = r_begin + trow;
-  int x = (int)(r % Wi);
-  long long tq = r / Wi;
-  int yy = (int)(tq % Hi);
-  long long n = tq / Hi;
-  const int dq = rpp / Wi, dr = rpp - dq * Wi;     // rpp = dq * Wi + dr
-  for (; r < r_end; r += rpp) {
-    f32x4 y[V4], dz[V4];
-    ldv_stream<V4>(Y + r * C + c, y);
-    pool_gradv<T>(dP, amax, n, yy, x, cv, Ho, Wo, C / V, dz);
-    x += dr; yy += dq;
-    if (x >= Wi) { x -= Wi; ++yy; }
-    while (yy >= Hi) { yy -= Hi; ++n; }
+  const int qr0 = blockIdx.x * rq;
+  const int qr1 = qr0 + rq < quad_rows ? qr0 + rq : quad_rows;
+  for (int qr = qr0; qr < qr1; ++qr) {
+    const int n = qr / Ho, qy = qr - n * Ho;
+    for (int it = threadIdx.x; it < items; it += nt) {
+      PoolQuad<T> q;
+      pool_quad<T>(dP, amax, Y, n, qy, it >> cv_log2, cv, Hi, Wi, Ho, Wo, CV, q);
 #pragma unroll
-    for (int k = 0; k < V4; ++k)
+      for (int w = 0; w < 4; ++w) {
+        const bool valid = ((w & 1) == 0 || q.vb) && ((w & 2) == 0 || q.va);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float g = fmaf(y[k][e], sc[k][e], sh[k][e]) > 0.f ? dz[k][e] : 0.f;
-        s1[k][e] += g;
-        s2[k][e] = fmaf(g, (y[k][e] - mu[k][e]) * is[k][e], s2[k][e]);
+        for (int k = 0; k < V4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yv = q.y[w][k][e];
+            const float g = (valid && fmaf(yv, sc[k][e], sh[k][e]) > 0.f) ? q.dz[w][k][e] : 0.f;
+            s1[k][e] += g;
+            s2[k][e] = fmaf(g, (yv - mu[k][e]) * is[k][e], s2[k][e]);
+          }
       }
+    }
   }
 #pragma unroll
-  for (int k = 0; k < V4; ++k) { red[0][k][threadIdx.x] = s1[k]; red[1][k][threadIdx.x] = s2[k]; }
+  for (int k = 0; k < V4; ++k) { pool_red[(0 * V4 + k) * nt + threadIdx.x] = s1[k]; pool_red[(1 * V4 + k) * nt + threadIdx.x] = s2[k]; }
   __syncthreads();
-  if (trow == 0) {
-    for (int q = 1; q < rpp; ++q)
+  // stage 2: G groups per channel vector, group g adds the threads g, g+G, ... of its vector; stage 3: one thread adds the groups
+  const int per_cv = nt >> cv_log2;
+  const int G = per_cv < 8 ? per_cv : 8;
+  if ((int)threadIdx.x < G * CV) {
+    const int g = threadIdx.x >> cv_log2;
 #pragma unroll
-      for (int k = 0; k < V4; ++k) { s1[k] += red[0][k][q * cpb + tcol]; s2[k] += red[1][k][q * cpb + tcol]; }
+    for (int k = 0; k < V4; ++k) { s1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = g; t < per_cv; t += G)
+#pragma unroll
+      for (int k = 0; k < V4; ++k) { s1[k] += pool_red[(0 * V4 + k) * nt + t * CV + cv]; s2[k] += pool_red[(1 * V4 + k) * nt + t * CV + cv]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G * CV) {
+#pragma unroll
+    for (int k = 0; k < V4; ++k) { pool_red[(0 * V4 + k) * nt + threadIdx.x] = s1[k]; pool_red[(1 * V4 + k) * nt + threadIdx.x] = s2[k]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < CV) {
+    for (int g = 1; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < V4; ++k) { s1[k] += pool_red[(0 * V4 + k) * nt + g * CV + cv]; s2[k] += pool_red[(1 * V4 + k) * nt + g * CV + cv]; }
 #pragma unroll
     for (int k = 0; k < V4; ++k) {
       st4(partials + ((long long)blockIdx.x * 2 + 0) * C + c + 4 * k, s1[k]);
@@ -950,21 +1090,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
   }
 }
 
-// pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool. One image row (n, y) per block: the pixel /
-// channel-vector split of an item is a shift (CV is a power of two), so there is no integer division per element.
+// pass 2: dY = scale * (g - c1 - yhat * c2) with g gathered through the max-pool; one quad row (n, qy) per block.
 template <class T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
-                                                                 const T* __restrict__ Y, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, const float* __restrict__ c1,
-                                                                 const float* __restrict__ c2, T* __restrict__ dY, int CV, int cv_log2,
-                                                                 int Hi, int Wi, int Ho, int Wo) {
+__global__ __launch_bounds__(1024) void bn_bwd_apply_pool_kernel(const T* __restrict__ dP, const unsigned char* __restrict__ amax,
+                                                                  const T* __restrict__ Y, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ c1,
+                                                                  const float* __restrict__ c2, T* __restrict__ dY, int CV, int cv_log2,
+                                                                  int Hi, int Wi, int Ho, int Wo) {
   constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
-  const int yy = blockIdx.x % Hi;
-  const long long n = blockIdx.x / Hi;
-  const long long row0 = (long long)blockIdx.x * Wi * CV;     // first vector item of this image row
-  const int items = Wi * CV;
-  // CV divides 256 (launcher): the thread's channel vector, hence its six coefficient vectors, are loop-invariant
+  const int n = blockIdx.x / Ho, qy = blockIdx.x - n * Ho;
+  const int items = Wo * CV;
   const int cv = threadIdx.x & (CV - 1);
   const int c = cv * V;
   f32x4 sc[V4], sh[V4], mu[V4], is[V4], k1[V4], k2[V4];
@@ -973,45 +1109,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restr
     sc[k] = ld4(scale + c + 4 * k); sh[k] = ld4(shift + c + 4 * k); mu[k] = ld4(mean + c + 4 * k); is[k] = ld4(invstd + c + 4 * k);
     k1[k] = ld4(c1 + c + 4 * k); k2[k] = ld4(c2 + c + 4 * k);
   }
-  for (int it = threadIdx.x; it < items; it += 256) {
-    const int x = it >> cv_log2;
-    const long long i = row0 + it;
-    f32x4 y[V4], dz[V4], o[V4];
-    ldv_stream<V4>(Y + i * V, y);
-    pool_gradv<T>(dP, amax, n, yy, x, cv, Ho, Wo, CV, dz);
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int qx = it >> cv_log2;
+    PoolQuad<T> q;
+    pool_quad<T>(dP, amax, Y, n, qy, qx, cv, Hi, Wi, Ho, Wo, CV, q);
+    const long long p = ((((long long)n * Hi + 2 * qy) * Wi + 2 * qx) * CV + cv) * V;
 #pragma unroll
-    for (int k = 0; k < V4; ++k)
+    for (int w = 0; w < 4; ++w) {
+      f32x4 o[V4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float g = fmaf(y[k][e], sc[k][e], sh[k][e]) > 0.f ? dz[k][e] : 0.f;
-        const float yh = (y[k][e] - mu[k][e]) * is[k][e];
-        o[k][e] = sc[k][e] * (g - k1[k][e] - yh * k2[k][e]);
-      }
-    stv<V4>(dY + i * V, o, true);
+      for (int k = 0; k < V4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yv = q.y[w][k][e];
+          const float g = fmaf(yv, sc[k][e], sh[k][e]) > 0.f ? q.dz[w][k][e] : 0.f;
+          const float yh = (yv - mu[k][e]) * is[k][e];
+          o[k][e] = sc[k][e] * (g - k1[k][e] - yh * k2[k][e]);
+        }
+      const bool valid = ((w & 1) == 0 || q.vb) && ((w & 2) == 0 || q.va);
+      if (valid) stv<V4>(dY + p + (long long)(w & 1) * CV * V + (long long)(w >> 1) * Wi * CV * V, o, true);
+    }
   }
 }
 
+// Quad rows per block of the pooled reduce: 8, or more when that would give more partial rows than the plain fp32 reduce of the
+// same tensor writes (the size every BatchNorm workspace is laid out for).
+static inline void pool_reduce_geometry(int N, int Hi, int Wi, int C, int* rq, int* nblk) {
+  const int Ho = (Hi + 2 - 3) / 2 + 1;
+  const int quad_rows = N * Ho;
+  const int cap = bn_bwd_partial_rows((long long)N * Hi * Wi, C, DT_F32);
+  int r = ceil_div(quad_rows, cap);
+  if (r < 8) r = 8;
+  *rq = r;
+  *nblk = ceil_div(quad_rows, r);
+}
+
 // rows of the partial buffer the pooled reduce writes
-int bn_bwd_pool_partial_rows(long long rows, int C, int dt) {
-  int cpb, rpb, nblk;
-  if (dt == DT_BF16) bwd_geometry16(rows, C, &cpb, &rpb, &nblk);
-  else bwd_geometry(rows, C, &cpb, &rpb, &nblk);
+int bn_bwd_pool_partial_rows(int N, int Hi, int Wi, int C) {
+  int rq, nblk;
+  pool_reduce_geometry(N, Hi, Wi, C, &rq, &nblk);
   return nblk;
 }
 
 int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
                               hipStream_t s) {
-  R3M_REQUIRE(is_pow2(C) && C >= 8, "bn_bwd_reduce_pool: C=%d must be a power of two >= 8", C);
+  R3M_REQUIRE(is_pow2(C) && C >= 8 && C <= 1024, "bn_bwd_reduce_pool: C=%d must be a power of two in [8, 1024]", C);
   const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-  const long long rows = (long long)N * Hi * Wi;
-  int cpb, rpb, nblk;
-  if (dt == DT_BF16) bwd_geometry16(rows, C, &cpb, &rpb, &nblk);
-  else bwd_geometry(rows, C, &cpb, &rpb, &nblk);
+  int rq, nblk;
+  pool_reduce_geometry(N, Hi, Wi, C, &rq, &nblk);
   DT_DISPATCH(dt, "bn_bwd_reduce_pool", {
-    constexpr int V = 4 * PoolVec<T>::V4;
-    hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), dim3(nblk, ceil_div(C / V, cpb)), dim3(256), 0, s, static_cast<const T*>(dP),
-                       amax, static_cast<const T*>(Y), scale, shift, mean, invstd, partials, rows, C, cpb, rpb, Hi, Wi, Ho, Wo);
+    constexpr int V4 = PoolVec<T>::V4, V = 4 * V4;
+    const int CV = C / V, nt = pool_row_threads(Wo * CV);
+    hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T>), dim3(nblk), dim3(nt), (size_t)2 * V4 * nt * sizeof(f32x4), s,
+                       static_cast<const T*>(dP), amax, static_cast<const T*>(Y), scale, shift, mean, invstd, partials, N * Ho, rq, C,
+                       CV, ilog2_exact(CV), Hi, Wi, Ho, Wo);
   });
   return check_launch("bn_bwd_reduce_pool");
 }
@@ -1023,10 +1175,10 @@ int launch_bn_bwd_apply_pool(const void* dP, const unsigned char* amax, const vo
   R3M_REQUIRE(is_pow2(C) && C >= 8 && C <= 1024, "bn_bwd_apply_pool: C=%d must be a power of two in [8, 1024]", C);
   DT_DISPATCH(dt, "bn_bwd_apply_pool", {
     constexpr int V = 4 * PoolVec<T>::V4;
-    int cv_log2 = 0;
-    while ((1 << cv_log2) < C / V) ++cv_log2;
-    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(N * Hi), dim3(256), 0, s, static_cast<const T*>(dP), amax,
-                       static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), C / V, cv_log2, Hi, Wi, Ho, Wo);
+    const int CV = C / V;
+    hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T>), dim3(N * Ho), dim3(pool_row_threads(Wo * CV)), 0, s, static_cast<const T*>(dP),
+                       amax, static_cast<const T*>(Y), scale, shift, mean, invstd, c1, c2, static_cast<T*>(dY), CV, ilog2_exact(CV), Hi, Wi,
+                       Ho, Wo);
   });
   return check_launch("bn_bwd_apply_pool");
 }

@@ -447,7 +447,7 @@ int r3m_bn_maxpool_bwd_dt(const void* dp, const unsigned char* am, const void* y
   float* c12 = reinterpret_cast<float*>(static_cast<char*>(ws) + bn_c12_off(rows, C));
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
   if (int e = launch_bn_bwd_reduce_pool(dp, am, y, scale, shift, mean, invstd, partial, N, Hi, Wi, C, dtype, S(stream))) return e;
-  const int prow = bn_bwd_pool_partial_rows(rows, C, dtype);
+  const int prow = bn_bwd_pool_partial_rows(N, Hi, Wi, C);
   if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
   if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
   return launch_bn_bwd_apply_pool(dp, am, y, scale, shift, mean, invstd, c12, c12 + C, dy, N, Hi, Wi, C, dtype, S(stream));

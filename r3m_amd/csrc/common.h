@@ -184,7 +184,7 @@ int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits
 // stem tail fused (Z0 / dZ0 never materialised)
 int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
                                int Wi, int C, int dt, hipStream_t s);
-int bn_bwd_pool_partial_rows(long long rows, int C, int dt);
+int bn_bwd_pool_partial_rows(int N, int Hi, int Wi, int C);
 int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
                               hipStream_t s);

@@ -183,7 +183,7 @@ Plan* plan_create(int size, int F, int dtype) {
     c.stats_rows = gather_gemm_grid_m(M, c.Co);
     long long pr = (long long)c.stats_rows * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
-    pr = (long long)(i == 0 ? bn_bwd_pool_partial_rows(M, c.Co, dtype) : bn_bwd_partial_rows(M, c.Co, dtype)) * 2 * c.Co;
+    pr = (long long)(i == 0 ? bn_bwd_pool_partial_rows(F, c.Ho, c.Wo, c.Co) : bn_bwd_partial_rows(M, c.Co, dtype)) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
     pr = ((long long)bnred_partial_rows(M) + 4) * 2 * c.Co;     // EPI_BNRED: one row per 64 result rows (+ one per stride-2 parity class)
     if (pr > partial_max) partial_max = pr;
@@ -695,7 +695,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         double* acc = reinterpret_cast<double*>(arena + P.acc_off);
         TRY(launch_bn_bwd_reduce_pool(Gp(0), am, arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), coef(c, L0, 0), coef(c, L0, 1), partial,
                                       F, 112, 112, 64, dt, s));
-        const int prow = bn_bwd_pool_partial_rows(rows, 64, dt);
+        const int prow = bn_bwd_pool_partial_rows(F, 112, 112, 64);
         TRY(launch_bn_stats_reduce(partial, prow, 64, acc, s));
         TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, grads + L0.gamma_off, grads + L0.beta_off, coef(c, L0, 4),
                                         coef(c, L0, 5), accumulate, 64, s));
