@@ -78,13 +78,87 @@ __global__ __launch_bounds__(256) void stem_prep16_crop_kernel(const T* __restri
   *reinterpret_cast<bf16x8*>(xn16 + i * 8) = o;
 }
 
+// x / d for a CONSTANT divisor, bit-identical to the IEEE quotient for d in {255, 0.229, 0.224, 0.225} and every float of
+// magnitude 2^-40 .. 512 (and 0): q0 = x * RN(1/d), one exact-residual correction. Checked exhaustively on the CPU for these
+// four divisors (tests/test_const_division.py); three operations instead of the ~12 of the generic expansion.
+__device__ __forceinline__ float div_const(float x, float d, float rcp) {
+#pragma clang fp contract(off)
+  const float q = x * rcp;
+  const float r = fmaf(-d, q, x);
+  return fmaf(r, rcp, q);
+}
+
+// uint8 clips (what the loader ships): the same values as the kernel above, cheaper to produce. A thread owns 8 whole pixels (24
+// elements, three 16-byte stores) so the horizontal sample position and weights are computed once per pixel instead of once
+// per element; p / 255 comes from a 256-entry table (p is a byte) and the two remaining divisions by constants use div_const.
+// Operation order per element is bilinear_sample + stem_normalize's (augment_dev.h); the GPU tests compare the two bit for bit.
+constexpr int XN_GROUPS = (XN_ROW + 23) / 24;      // 30 groups of 24 elements; the last one holds 8 (padding) elements
+__global__ __launch_bounds__(256) void stem_prep16_crop_u8_kernel(const unsigned char* __restrict__ raw, const int* __restrict__ boxes,
+                                                                   bf16_t* __restrict__ xn16, long long total, int Hi, int Wi, int fpb) {
+#pragma clang fp contract(off)
+  __shared__ float lut[256];
+  lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i % XN_GROUPS);
+  long long t = i / XN_GROUPS;
+  const int r = (int)(t % XN_ROWS);
+  const long long f = t / XN_ROWS;
+  bf16_t* dst = xn16 + (f * XN_ROWS + r) * XN_ROW + g * 24;
+  const int nst = g == XN_GROUPS - 1 ? (XN_ROW - 24 * (XN_GROUPS - 1)) / 8 : 3;
+  const int iy = r - 3;
+  bf16x8 o[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[q][e] = (bf16_t)0.f;
+  if ((unsigned)iy < 224u && g * 8 - 3 < 224) {
+    const int* b = boxes + (f / fpb) * 4;
+    const int top = b[0], left = b[1], bh = b[2], bw = b[3];
+    const float sy = fmaxf(fmaf((float)iy + 0.5f, (float)bh / 224.0f, -0.5f), 0.f);
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < bh - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const float xscale = (float)bw / 224.0f;
+    const long long plane = (long long)Hi * Wi;
+    const unsigned char* p0 = raw + f * 3 * plane + (long long)(top + y0) * Wi + left;
+    const unsigned char* p1 = raw + f * 3 * plane + (long long)(top + y1) * Wi + left;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ix = g * 8 - 3 + k;
+      if ((unsigned)ix >= 224u) continue;
+      const float sx = fmaxf(fmaf((float)ix + 0.5f, xscale, -0.5f), 0.f);
+      const int x0 = (int)sx;
+      const int x1 = x0 + (x0 < bw - 1 ? 1 : 0);
+      const float lx = sx - (float)x0, hx = 1.f - lx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v00 = lut[p0[c * plane + x0]], v01 = lut[p0[c * plane + x1]];
+        const float v10 = lut[p1[c * plane + x0]], v11 = lut[p1[c * plane + x1]];
+        const float t0 = fmaf(hx, v00, lx * v01);
+        const float t1 = fmaf(hx, v10, lx * v11);
+        const float v = fmaf(hy, t0, ly * t1) * 255.0f;
+        const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+        const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+        const float rsd = c == 0 ? 1.0f / 0.229f : (c == 1 ? 1.0f / 0.224f : 1.0f / 0.225f);
+        const float n = div_const(div_const(v, 255.0f, 1.0f / 255.0f) - mean, sd, rsd);
+        o[(k * 3 + c) >> 3][(k * 3 + c) & 7] = (bf16_t)n;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q < nst) *reinterpret_cast<bf16x8*>(dst + q * 8) = o[q];
+}
+
 int launch_stem_prep16_crop(const FrameSource& src, void* xn16, int F, hipStream_t s) {
   const long long total = (long long)F * XN_ROWS * (XN_ROW / 8);
-  if (src.is_u8)
-    hipLaunchKernelGGL((stem_prep16_crop_kernel<unsigned char>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
-                       static_cast<const unsigned char*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
-                       src.frames_per_box);
-  else
+  if (src.is_u8) {
+    const long long tg = (long long)F * XN_ROWS * XN_GROUPS;
+    hipLaunchKernelGGL(stem_prep16_crop_u8_kernel, dim3(ceil_div(tg, 256)), dim3(256), 0, s, static_cast<const unsigned char*>(src.frames),
+                       src.boxes, reinterpret_cast<bf16_t*>(xn16), tg, src.Hi, src.Wi, src.frames_per_box);
+  } else
     hipLaunchKernelGGL((stem_prep16_crop_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
                        static_cast<const float*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
                        src.frames_per_box);
