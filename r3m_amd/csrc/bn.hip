@@ -126,29 +126,37 @@ int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc, 
   return check_launch("bn_stats_reduce");
 }
 
-// Sum the S fp64 slices of acc[S][2][C] for one channel. Block = 64 channels x 4 slice groups (group g adds slices g, g+4, ...,
-// combined in group order -> deterministic); returns true for the thread that owns the channel's totals. A single thread
-// walking 64 dependent slices made these per-layer kernels 19 us each, ~4 ms per step.
+// Sum the S fp64 slices of acc[S][2][C] for one channel. Block = 64 channels x SG slice groups (group g adds slices g, g+SG, ...,
+// combined in group order -> deterministic); returns true for the thread that owns the channel's totals. These per-layer
+// kernels are pure latency: one thread walking 64 dependent slices made them 19 us each (~4 ms per step), 4 groups 15 us
+// (S is up to 256); 16 groups with the loads of four slices in flight: see DESIGN.md §5.
+constexpr int SG = 16;
 __device__ __forceinline__ bool slice_totals(const double* __restrict__ acc, int S, int C, int* c_out, double* s_out, double* ss_out) {
-  __shared__ double red[2][4][64];
+  __shared__ double red[2][SG][64];
   const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int i = g; i < S; i += 4) {
+  if (c < C) {
+#pragma unroll 4
+    for (int i = g; i < S; i += SG) {
       s += acc[((long long)i * 2 + 0) * C + c];
       ss += acc[((long long)i * 2 + 1) * C + c];
     }
+  }
   red[0][g][tx] = s;
   red[1][g][tx] = ss;
   __syncthreads();
   *c_out = c;
-  *s_out = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-  *ss_out = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  s = red[0][0][tx];
+  ss = red[1][0][tx];
+#pragma unroll
+  for (int k = 1; k < SG; ++k) { s += red[0][k][tx]; ss += red[1][k][tx]; }
+  *s_out = s;
+  *ss_out = ss;
   return g == 0 && c < C;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
+__global__ __launch_bounds__(64 * SG) void bn_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
                                                            double unbias, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float momentum, float eps,
@@ -180,7 +188,7 @@ int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, c
                             float* invstd, float* scale, float* shift, int C, hipStream_t s) {
   const double inv_count = 1.0 / (double)count;
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows, C), inv_count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * SG), 0, s, acc, reduce_slices(stat_rows, C), inv_count,
                      unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
   return check_launch("bn_finalize");
 }
@@ -528,7 +536,7 @@ int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbit
   return check_launch("bn_bwd_reduce");
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
+__global__ __launch_bounds__(64 * SG) void bn_bwd_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
                                                                int use_batch_stats, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ c1,
                                                                float* __restrict__ c2, int accumulate, int C,
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
                                 float* dbeta, float* c1, float* c2, int accumulate, int C, hipStream_t s,
                                 const float* second_sum_scale) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, acc, reduce_slices(stat_rows, C),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * SG), 0, s, acc, reduce_slices(stat_rows, C),
                      1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C, second_sum_scale);
   return check_launch("bn_bwd_finalize");
 }
