@@ -671,62 +671,80 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
     b_left = rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB;
   }
   const int b_stepb = BK * p.Ci * 2;
+  const int pixb = p.Ci * 2;                                    // bytes between the X rows of neighbouring taps (one pixel)
+  const int rowb = p.Wi * pixb;
+  const int kh_p = kh - p.pad, kw_p = kw0 - p.pad;
+  // 3x3 / strided layers: a lane tracks the INPUT coordinates of its row's output pixel (ys = oy * stride, xs = ox * stride) and
+  // their byte position pos = ys * rowb + xs * pixb by additions only (a K step advances (oy, ox) by a block-uniform amount),
+  // so there is no integer multiply in the K loop (v_mul_lo_u32 issues at a quarter of the rate: four per piece were ~60 cycles).
+  const int xs_wrap = p.Wo * p.stride, ys_wrap = p.Ho * p.stride;
+  const int adv_xs = r64 * p.stride, adv_ys = q64 * p.stride;
+  const int adv_pos = adv_ys * rowb + adv_xs * pixb;
+  const int wrapx_pos = p.stride * rowb - xs_wrap * pixb;       // ox wrapped: one output row down, Wo pixels back
+  const int wrapy_pos = ys_wrap * rowb;                         // oy wrapped: next frame (b_off carries the frame)
+  const int tap_pos = kh_p * rowb + kw_p * pixb;
   int b_m[BJ];
   unsigned b_off[BJ];      // simple rows: constant per-lane offset; otherwise byte offset of the row's frame from b_base (+ channels)
-  int xoy[BJ], xox[BJ];
+  int ys[BJ], xs[BJ], pos[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     b_m[j] = ms + wave * WR + j * B_RPI + b_k;
-    xoy[j] = 0; xox[j] = 0;
+    ys[j] = 0; xs[j] = 0; pos[j] = 0;
     if (p.simple_rows) {
       b_off[j] = (unsigned)((wave * WR + j * B_RPI + b_k) * p.Ci * 2) + b_chan;
     } else {
       const int n = b_m[j] / hw;
       const int rem = b_m[j] - n * hw;
-      xoy[j] = rem / p.Wo;
-      xox[j] = rem - xoy[j] * p.Wo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      ys[j] = oy * p.stride; xs[j] = ox * p.stride;
+      pos[j] = ys[j] * rowb + xs[j] * pixb;
       b_off[j] = (unsigned)(n - n0) * imgb + b_chan;
     }
   }
-  const int pixb = p.Ci * 2;                                    // bytes between the X rows of neighbouring taps (one pixel)
-  const int rowb = p.Wi * pixb;
-  const int kh_p = kh - p.pad, kw_p = kw0 - p.pad;
 
+  // NT = 3 runs at the register limit: there the descriptor words are pinned to scalar registers (conv_dev.h buf_dma16_uniform)
+  auto dma = [&](const char* base, int bytes, unsigned char* lds, unsigned voff) __attribute__((always_inline)) {
+    if constexpr (NT == 3) buf_dma16_uniform(base, bytes, lds, voff);
+    else buf_dma16(base, bytes, lds, voff);
+  };
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       unsigned char* la = smem + stage * STAGE + (wave * WR + j * A_RPI) * A_ROWB;
-      buf_dma16(a_base, a_left, la, a_voff[j]);
+      dma(a_base, a_left, la, a_voff[j]);
     } else {
       constexpr int j = pc - AJ;
       unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * WR + j * B_RPI) * B_ROWB;
       if (p.simple_rows) {
-        buf_dma16(b_base, b_left, lb, b_off[j]);
+        dma(b_base, b_left, lb, b_off[j]);
       } else {
-        const int iy = xoy[j] * p.stride + kh_p, ix0 = xox[j] * p.stride + kw_p;
+        const int iy = ys[j] + kh_p, ix0 = xs[j] + kw_p;
         const bool rowok = (unsigned)iy < (unsigned)p.Hi;
-        const unsigned off0 = b_off[j] + (unsigned)(iy * rowb + ix0 * pixb);     // garbage when the tap is padding: not used then
+        const unsigned off0 = b_off[j] + (unsigned)(pos[j] + tap_pos);           // garbage when the tap is padding: not used then
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const bool in = rowok && ((unsigned)(ix0 + t) < (unsigned)p.Wi);
-          buf_dma16(b_base, b_left, lb + t * B_TILE, in ? off0 + (unsigned)(t * pixb) : BUF_OOB);
+          dma(b_base, b_left, lb + t * B_TILE, in ? off0 + (unsigned)(t * pixb) : BUF_OOB);
         }
         if (fast_adv) {
-          int ox = xox[j] + r64, oy = xoy[j] + q64;
-          const bool cx = ox >= p.Wo;
-          ox = cx ? ox - p.Wo : ox;
-          oy = cx ? oy + 1 : oy;
-          const bool cy = oy >= p.Ho;
-          oy = cy ? oy - p.Ho : oy;
+          int x = xs[j] + adv_xs, y = ys[j] + adv_ys, ps = pos[j] + adv_pos;
+          const bool cx = x >= xs_wrap;
+          x = cx ? x - xs_wrap : x;
+          y = cx ? y + p.stride : y;
+          ps = cx ? ps + wrapx_pos : ps;
+          const bool cy = y >= ys_wrap;
+          y = cy ? y - ys_wrap : y;
+          ps = cy ? ps - wrapy_pos : ps;
           b_off[j] = cy ? b_off[j] + imgb : b_off[j];
-          xox[j] = ox; xoy[j] = oy;
+          xs[j] = x; ys[j] = y; pos[j] = ps;
         } else {
           b_m[j] += BK;
           const int n = b_m[j] / hw;
           const int rem = b_m[j] - n * hw;
-          xoy[j] = rem / p.Wo;
-          xox[j] = rem - xoy[j] * p.Wo;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          ys[j] = oy * p.stride; xs[j] = ox * p.stride;
+          pos[j] = ys[j] * rowb + xs[j] * pixb;
           b_off[j] = (unsigned)(n - n0) * imgb + b_chan;
         }
       }

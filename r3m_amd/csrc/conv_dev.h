@@ -477,6 +477,18 @@ constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count belo
 // One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
 // descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
 // builtin and would silently drop the kernels that call it).
+// buf_dma16 with the descriptor words forced into scalar registers. Under register pressure (the 192-accumulator bf16 weight
+// gradient) the compiler parked the loop-carried base / size in VECTOR registers and wrapped every DMA instruction in a waterfall
+// loop (4 readfirstlanes, two 64-bit compares, an exec save/restore and a branch: 12 instructions, 36 loops in that kernel).
+__device__ __forceinline__ void buf_dma16_uniform(const void* base, int bytes, void* lds, unsigned voff, int soff = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long v = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  void* b = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(b, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000),
+                                           (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
 __device__ __forceinline__ void buf_dma16(const void* base, int bytes, void* lds, unsigned voff, int soff = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // soff: wave-uniform byte offset added to the address (an SGPR operand of the instruction). Callers only put offsets there that
