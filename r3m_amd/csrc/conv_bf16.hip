@@ -573,6 +573,9 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
     rc = big ? (gg16_big() == 64 ? gg16_launch<256, 128, 2, 2, 2, 64>(p, gridb, s) : gg16_launch<256, 128, 2, 2, 2, 32>(p, gridb, s))
          : ring ? gg16_launch<128, 128, 2, 4, 3>(p, grid, s) : w8 ? gg16_launch<128, 128, 2, 4, 2>(p, grid, s)
          : (nk == 1 && gg16_single()) ? gg16_launch<128, 128, 2, 2, 1>(p, grid, s)
+#ifdef R3M_PROBES
+         : (gg16_bk32(p, true) && R3M_ENV_INT("R3M_BF16_NST3", 0)) ? gg16_launch<128, 128, 2, 2, 3, 32>(p, grid, s)   // 3-stage ring, 48 KB: 3 blocks/CU
+#endif
          : gg16_bk32(p, true) ? gg16_launch<128, 128, 2, 2, 2, 32>(p, grid, s) : gg16_launch<128, 128, 2, 2, 2>(p, grid, s);
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
