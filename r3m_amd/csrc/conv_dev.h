@@ -37,6 +37,14 @@ __device__ __forceinline__ void st4_out(bf16_t* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
 #endif
 }
+constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count used here: such a lane's 16 bytes are dropped / arrive as zeros
+// 16-byte store through a buffer descriptor [base, base + bytes): wave-uniform base, 32-bit per-lane byte offset, lanes whose
+// offset is past the end store nothing. (Target builtins stay inside device-compile guards: see buf_dma16.)
+__device__ __forceinline__ void buf_store16(void* base, int bytes, unsigned voff, epi_u32x4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), voff, 0, R3M_EPI_NT ? 2 : 0);
+#endif
+}
 __device__ __forceinline__ void st8_out(bf16_t* p, bf16x8 v) {
 #if R3M_EPI_NT
   __builtin_nontemporal_store(__builtin_bit_cast(epi_u32x4, v), reinterpret_cast<epi_u32x4*>(p));
@@ -383,15 +391,40 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
           for (int r = 0; r < 16; ++r)
             slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[ps * TMP + tm][tn][r];
       __builtin_amdgcn_wave_barrier();
+      bool stored = false;
+      if constexpr ((EPI & EPI_BNRED) == 0) {
+        // Contiguous output rows (every forward, stride-1 dgrad): the wave's 64 rows go out through a buffer descriptor that starts
+        // at its first row and ends with the tensor — a lane's address is a 32-bit offset advanced by one add per store, rows past
+        // M fall off the descriptor's end. (The generic path below costs a 64-bit multiply-add, a compare and an exec mask per
+        // store: ~12 instructions x 16 stores per lane; this epilogue is as long as the MFMAs of a K = 256 tile.)
+        const int rowbase = m0 + (__builtin_amdgcn_readfirstlane(wm) * TM + ps * TMP) * 32;
+        if (out_simple && rowbase < p.M) {
+          const long long left = (long long)(p.M - rowbase) * p.Nc * 2;
+          bf16_t* rbase = outp + (long long)rowbase * p.Nc;
+          const int rbytes = left < (long long)BUF_OOB ? (int)left : (int)BUF_OOB;
+          unsigned voff = gcol < p.Nc ? (unsigned)((erow * p.Nc + gcol) * 2) : BUF_OOB;
+          const unsigned vstep = (unsigned)(RPI * p.Nc * 2);
 #pragma unroll
-      for (int it = 0; it < TMP * 32 / RPI; ++it) {
-        const int lr = it * RPI + erow;
-        const int row = m0 + (wm * TM + ps * TMP) * 32 + lr;
-        if (row < p.M && gcol < p.Nc) {
-          const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
-          const long long eo = row_off(row) + gcol;
-          st8_out(outp + eo, ov);
-          if constexpr ((EPI & EPI_BNRED) != 0) bnred8(ov, eo);
+          for (int it = 0; it < TMP * 32 / RPI; ++it) {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + (it * RPI + erow) * CSH + ecol);
+            buf_store16(rbase, rbytes, voff, __builtin_bit_cast(epi_u32x4, ov));
+            voff += vstep;
+          }
+          stored = true;
+        }
+        if (out_simple) stored = true;       // rowbase >= M: nothing of this pass is inside the tensor
+      }
+      if (!stored) {
+#pragma unroll
+        for (int it = 0; it < TMP * 32 / RPI; ++it) {
+          const int lr = it * RPI + erow;
+          const int row = m0 + (wm * TM + ps * TMP) * 32 + lr;
+          if (row < p.M && gcol < p.Nc) {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
+            const long long eo = row_off(row) + gcol;
+            st8_out(outp + eo, ov);
+            if constexpr ((EPI & EPI_BNRED) != 0) bnred8(ov, eo);
+          }
         }
       }
       if constexpr ((EPI & EPI_BNRED) != 0) {
@@ -472,7 +505,6 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
 }
 
 // ---- LDS DMA through a buffer descriptor (round 3; see the wgrad kernels) ----
-constexpr unsigned BUF_OOB = 0x7FFFF000u;   // >= any descriptor byte count below: such a lane's 16 bytes arrive as zeros
 
 // One `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff (zeros when voff >= bytes) to lds + 16 * lane. The
 // descriptor (base, bytes) must be wave-uniform. The body exists in the device pass only (the host pass of hipcc has no such
