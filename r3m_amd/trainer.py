@@ -7,7 +7,8 @@
     reference's order (language: (a,b,c) x 3 at :86-92, then TCN: (es0, es2) x 3 at :136-137), uploaded once;
   * the 15 reward-head evaluations are one batched [15B, 2D+768] GEMM chain (models_language.LanguageReward.batched);
     the frozen sentence features are computed once per step instead of 15 times (trainer.py:72-92 -> models_r3m.py:78-81);
-  * all metrics come back in ONE device->host copy instead of ~10 .item() syncs.
+  * all metrics come back in ONE device->host copy instead of ~10 .item() syncs, queued before the backward pass so that the
+    host does not wait for the optimizer step (the next step is queued behind it).
 """
 import time
 
@@ -21,6 +22,7 @@ epsilon = 1e-8
 class Trainer:
     def __init__(self, eval_freq):
         self.eval_freq = eval_freq
+        self._mh = None          # pinned host copy of the step's metrics
 
     def update(self, model, batch, step, eval=False):
         t0 = time.time()
@@ -68,6 +70,17 @@ class Trainer:
         full_loss, m = ops.r3m_loss(alle, tcn_perm, core.l2weight, core.l1weight, core.tcnweight, l2dist=core.l2dist,
                                     scores=scores, mask=mask, langweight=core.langweight)
         t6 = time.time()
+        # The metrics are final once the objective's forward has run: their device->host copy is queued HERE, in front of the
+        # backward pass, and the host waits for that copy only — it returns while the GPU still works through backward + Adam and
+        # queues the next step behind them (stream order keeps the weights consistent). Waiting for the whole step instead left
+        # the GPU idle for ~0.5 ms per step between Adam and the next step's first kernel (rocprofv3 trace, bf16 ResNet-50).
+        ready = None
+        if m.is_cuda:
+            if getattr(self, "_mh", None) is None or self._mh.numel() != m.numel():
+                self._mh = torch.empty(m.numel(), dtype=m.dtype, pin_memory=True)
+            self._mh.copy_(m.detach().reshape(-1), non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
         if not eval:
             core.encoder_opt.zero_grad()
             full_loss.backward()
@@ -76,7 +89,11 @@ class Trainer:
                 sync()
             core.encoder_opt.step()
 
-        mh = m.tolist()   # the step's single device->host sync
+        if ready is not None:
+            ready.synchronize()          # the step's single host wait
+            mh = self._mh.tolist()
+        else:
+            mh = m.tolist()
         for k in ("l2loss", "l1loss", "l0loss"):
             metrics[k] = mh[ops.METRIC_SLOTS[k]]
         if core.langweight > 0:
