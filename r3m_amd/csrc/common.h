@@ -137,6 +137,8 @@ int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher wi
 int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_pick_split(int M, int Co, int Ci, int T);
 int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s);
+struct WtEntry { long long w_off, wt_off; int Co, T, Ci, pad_; };
+int launch_transpose_w_all(const float* params, void* wt, const WtEntry* tab, const int* tile0, int n, int tiles, int dt, hipStream_t s);
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
 int launch_stem_prep(const float* x_nchw, float* xn, int F, hipStream_t s);
 struct FrameSource;   // augment_dev.h: raw clips + crop boxes

@@ -1978,6 +1978,45 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
   }
 }
 
+// Every dgrad weight image of a network in ONE launch (the engine ran one 5 us transpose per conv layer and step: 52 launches for
+// ResNet-50). tab[l] = {w_off, wt_off, Co, T, Ci}: Wt_l[ci][t][co] = W_l[co][t][ci] with W_l at params + w_off and Wt_l at
+// wt + wt_off (elements of the output type); tile0[l] = first 32 x 32 tile (block) of layer l, tile0[n] = grid size.
+template <class OT>
+__global__ __launch_bounds__(256) void transpose_w_all_kernel(const float* __restrict__ params, OT* __restrict__ wt,
+                                                               const WtEntry* __restrict__ tab, const int* __restrict__ tile0, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;                 // last l with tile0[l] <= blockIdx.x (block-uniform binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WtEntry e = tab[lo];
+  const int local = blockIdx.x - tile0[lo];
+  const int tci = (e.Ci + 31) / 32, tco = (e.Co + 31) / 32;
+  const int ci0 = (local % tci) * 32, co0 = ((local / tci) % tco) * 32, t = local / (tci * tco);
+  const float* W = params + e.w_off;
+  OT* Wt = wt + e.wt_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < e.Co && ci < e.Ci) ? W[((long long)co * e.T + t) * e.Ci + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < e.Ci && co < e.Co) Wt[((long long)ci * e.T + t) * e.Co + co] = (OT)tile[tx][r];
+  }
+}
+
+int launch_transpose_w_all(const float* params, void* wt, const WtEntry* tab, const int* tile0, int n, int tiles, int dt, hipStream_t s) {
+  if (n <= 0 || tiles <= 0) return 0;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((transpose_w_all_kernel<bf16_t>), dim3(tiles), dim3(256), 0, s, params, static_cast<bf16_t*>(wt), tab, tile0, n);
+  else
+    hipLaunchKernelGGL((transpose_w_all_kernel<float>), dim3(tiles), dim3(256), 0, s, params, static_cast<float*>(wt), tab, tile0, n);
+  return check_launch("transpose_w_all");
+}
+
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s) {
   hipLaunchKernelGGL(transpose_w_kernel, dim3(ceil_div(Ci, 32), ceil_div(Co, 32), T), dim3(256), 0, s, W, Wt, Co, T, Ci);
   return check_launch("transpose_w");

@@ -30,6 +30,7 @@ struct ConvSpec {
   long long Z_off;                        // arena: activated output, -1 when the block epilogue produces it
   long long coef_off;                     // arena: mean, invstd, scale, shift, c1, c2  (6*Co floats)
   int stats_rows;                         // row blocks of the forward GEMM (BatchNorm partials)
+  long long wt_off = 0;                   // dgrad weight image [Ci][k*k][Co] inside the plan's Wt region (elements of the activation type)
 };
 
 struct BlockSpec {
@@ -83,6 +84,12 @@ struct Plan {
   // 0,1,2,3 after ONE forward: next_stage is what the following call must begin with (0 = a backward may (re)start, -1 = no
   // forward has run yet).
   int next_stage = -1;
+  // dgrad weight images of all layers, rebuilt by ONE launch at the start of each backward (launch_transpose_w_all)
+  std::vector<WtEntry> wt_tab;
+  std::vector<int> wt_tile0;
+  long long wt_elems = 0;
+  WtEntry* d_wt_tab = nullptr;             // device copies, made at the first backward (plan creation needs no GPU)
+  int* d_wt_tile0 = nullptr;
 };
 
 static long long align64(long long x) { return (x + 63) / 64 * 64; }
@@ -210,7 +217,21 @@ Plan* plan_create(int size, int F, int dtype) {
   }
   P.partial_off = take(partial_max);
   P.acc_off = take(64LL * 2 * 2048 * 2);  // doubles: 64 slices x 2 x Cmax, in float units x2
-  P.wt_off = take(wmax);
+  {   // one dgrad weight image per conv layer after the stem (the stem has no input gradient)
+    int tiles = 0;
+    long long we = 0;
+    for (size_t i = 1; i < P.convs.size(); ++i) {
+      ConvSpec& c = P.convs[i];
+      c.wt_off = we;
+      P.wt_tab.push_back(WtEntry{c.w_off, we, c.Co, c.k * c.k, c.Ci, 0});
+      P.wt_tile0.push_back(tiles);
+      tiles += ceil_div(c.Ci, 32) * ceil_div(c.Co, 32) * c.k * c.k;
+      we += align64((long long)c.Co * c.k * c.k * c.Ci);
+    }
+    P.wt_tile0.push_back(tiles);
+    P.wt_elems = we;
+    P.wt_off = take(dtype == DT_BF16 ? (we + 1) / 2 : we);
+  }
   if (dtype == DT_BF16) P.w16_off = take((P.n_params + 1) / 2);
   P.wgp_off = take(wgp_max);
   P.gmax = gmax;
@@ -504,9 +525,9 @@ static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
 // (block outputs) or null (mask recomputed from Y). *fused_rows_out receives the partial-row count (0 = not fused).
 static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flags, const float* add0, const unsigned* addbits,
                  const ConvSpec* bn_of = nullptr, const unsigned* bn_bits = nullptr, int* fused_rows_out = nullptr) {
-  float* Wt = c.arena + c.P.wt_off;
-  if (c.dt == DT_BF16) TRY(launch_transpose_w_bf16(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
-  else TRY(launch_transpose_w(c.params + L.w_off, Wt, L.Co, L.k * L.k, L.Ci, c.s));
+  // the layer's [Ci][k*k][Co] weight image was built at the start of this backward (plan_backward, stage 0)
+  float* Wt = c.dt == DT_BF16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c.arena + c.P.wt_off) + L.wt_off)
+                              : c.arena + c.P.wt_off + L.wt_off;
   if (fused_rows_out) *fused_rows_out = 0;
   // 1x1 stride-2 dgrads leave three of four parity classes without taps (plain zero / no-op launches): not fused
   const bool fuse = bn_of && fused_rows_out && c.P.fuse_bnred && !(L.stride == 2 && L.k == 1);
@@ -571,6 +592,18 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
               "stage 0 restarts)", stage_begin, P.next_stage);
   P.next_stage = -2;           // poisoned while in flight: after a failed call only stage 0 (a restart) is accepted
   TRY(side_init(P));
+  if (stage_begin == 0) {       // the weights are final since the last optimizer step: all dgrad weight images in one launch
+    if (!P.d_wt_tab) {
+      const size_t tb = P.wt_tab.size() * sizeof(WtEntry), ib = P.wt_tile0.size() * sizeof(int);
+      if (hipMalloc(reinterpret_cast<void**>(&P.d_wt_tab), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P.d_wt_tile0), ib) != hipSuccess ||
+          hipMemcpy(P.d_wt_tab, P.wt_tab.data(), tb, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(P.d_wt_tile0, P.wt_tile0.data(), ib, hipMemcpyHostToDevice) != hipSuccess) {
+        set_last_error("resnet_backward: cannot allocate the weight-image table");
+        return 1;
+      }
+    }
+    TRY(launch_transpose_w_all(params, arena + P.wt_off, P.d_wt_tab, P.d_wt_tile0, (int)P.wt_tab.size(), P.wt_tile0.back(), P.dtype, s));
+  }
   const bool side_on = P.use_side && P.side;
   Ctx cs = c;                       // context whose launches go to the side stream
   cs.s = side_on ? P.side : s;
@@ -745,6 +778,8 @@ void plan_destroy(Plan* P) {
     for (hipEvent_t ev : {P->ev_dy, P->ev_wg[0], P->ev_wg[1], P->ev_join})
       if (ev) (void)hipEventDestroy(ev);
   }
+  if (P->d_wt_tab) (void)hipFree(P->d_wt_tab);
+  if (P->d_wt_tile0) (void)hipFree(P->d_wt_tile0);
   delete P;
 }
 int* plan_gd(Plan* P) { return &P->gd; }
