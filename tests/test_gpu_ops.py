@@ -311,34 +311,34 @@ def test_adam_matches_torch(hip):
 
 
 @pytest.mark.parametrize("dt", [0, 1], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("N,H,C", [(2, 112, 64), (3, 9, 64), (1, 10, 128)])
-def test_stem_tail_fused_equals_unfused(hip, N, H, C, dt):
+@pytest.mark.parametrize("N,H,W,C", [(2, 112, 112, 64), (3, 9, 9, 64), (1, 10, 10, 128), (2, 12, 9, 64), (2, 7, 16, 32)])
+def test_stem_tail_fused_equals_unfused(hip, N, H, W, C, dt):
     """BN+ReLU+MaxPool fused (what the engine runs) vs the separate operators, bit for bit: pooled values, argmax bytes,
     dY, dgamma, dbeta. Post-BN values have plenty of exact zeros (ReLU) -> ties in the windows are exercised."""
     tdt = torch.float32 if dt == 0 else torch.bfloat16
-    rows = N * H * H
+    rows = N * H * W
     y = rnd((rows, C), 61, -2.0, 2.0).to(DEV).to(tdt)
     yf = y.float()
     m, v = yf.mean(0), yf.var(0, unbiased=False)
     inv = 1.0 / torch.sqrt(v + 1e-5)
     gam, bet = rnd((C,), 62, 0.5, 1.5).to(DEV), rnd((C,), 63, -0.3, 0.3).to(DEV)
     coef = torch.stack([m, inv, gam * inv, bet - m * gam * inv]).contiguous()
-    Ho = (H + 2 - 3) // 2 + 1
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     # unfused
     z = torch.empty((rows, C), dtype=tdt, device=DEV)
     assert hip.r3m_bn_act_fwd_dt(y.data_ptr(), coef.data_ptr(), None, None, None, z.data_ptr(), rows, C, 1, None, dt, st()) == 0
-    p0 = torch.empty((N, Ho, Ho, C), dtype=tdt, device=DEV)
-    a0 = torch.empty((N, Ho, Ho, C), dtype=torch.uint8, device=DEV)
-    assert hip.r3m_maxpool_fwd_dt(z.data_ptr(), p0.data_ptr(), a0.data_ptr(), N, H, H, C, dt, st()) == 0
+    p0 = torch.empty((N, Ho, Wo, C), dtype=tdt, device=DEV)
+    a0 = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=DEV)
+    assert hip.r3m_maxpool_fwd_dt(z.data_ptr(), p0.data_ptr(), a0.data_ptr(), N, H, W, C, dt, st()) == 0
     # fused
     p1 = torch.empty_like(p0)
     a1 = torch.empty_like(a0)
-    assert hip.r3m_bn_relu_maxpool_fwd_dt(y.data_ptr(), coef.data_ptr(), p1.data_ptr(), a1.data_ptr(), N, H, H, C, dt, st()) == 0, hip.r3m_last_error()
+    assert hip.r3m_bn_relu_maxpool_fwd_dt(y.data_ptr(), coef.data_ptr(), p1.data_ptr(), a1.data_ptr(), N, H, W, C, dt, st()) == 0, hip.r3m_last_error()
     assert torch.equal(p0, p1) and torch.equal(a0, a1)
     # backward
-    dp = rnd((N, Ho, Ho, C), 64).to(DEV).to(tdt)
+    dp = rnd((N, Ho, Wo, C), 64).to(DEV).to(tdt)
     dz = torch.empty((rows, C), dtype=tdt, device=DEV)
-    assert hip.r3m_maxpool_bwd_dt(dp.data_ptr(), a0.data_ptr(), dz.data_ptr(), N, H, H, C, dt, st()) == 0
+    assert hip.r3m_maxpool_bwd_dt(dp.data_ptr(), a0.data_ptr(), dz.data_ptr(), N, H, W, C, dt, st()) == 0
     wsb = hip.r3m_bn_workspace_bytes(rows, C)
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     dg0, db0, dy0 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty((rows, C), dtype=tdt, device=DEV)
@@ -346,7 +346,7 @@ def test_stem_tail_fused_equals_unfused(hip, N, H, C, dt):
                              ws.data_ptr(), wsb, rows, C, 1, 0, dt, st()) == 0
     dg1, db1, dy1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty((rows, C), dtype=tdt, device=DEV)
     assert hip.r3m_bn_maxpool_bwd_dt(dp.data_ptr(), a1.data_ptr(), y.data_ptr(), coef.data_ptr(), dg1.data_ptr(), db1.data_ptr(),
-                                     dy1.data_ptr(), ws.data_ptr(), wsb, N, H, H, C, 1, 0, dt, st()) == 0, hip.r3m_last_error()
+                                     dy1.data_ptr(), ws.data_ptr(), wsb, N, H, W, C, 1, 0, dt, st()) == 0, hip.r3m_last_error()
     # the parameter gradients are sums in a different (but fixed) order between the two reduce kernels
     assert rel_err(dg1.cpu().numpy(), dg0.cpu().numpy())[0] < 1e-5 and rel_err(db1.cpu().numpy(), db0.cpu().numpy())[0] < 1e-5
     assert rel_err(dy1.float().cpu().numpy(), dy0.float().cpu().numpy())[0] < (1e-5 if dt == 0 else 2.0 ** -7)
