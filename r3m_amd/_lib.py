@@ -92,6 +92,8 @@ SIGNATURES = {
     "r3m_langrew_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "r3m_langrew_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_backward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_forward_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "r3m_langrew_backward_dt": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_call_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "r3m_langrew_call_forward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_f]),
     "r3m_langrew_call_backward": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_i, c_i, c_i, c_i, c_i, c_f]),

@@ -149,9 +149,9 @@ int launch_resize_crop(const void* in, int in_is_u8, float* out, long long N, in
 long long langrew_num_params(int D, int H, int LD);
 size_t langrew_ws_floats(int B, int D, int H, int LD);
 int langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, float* ws, int B,
-                    int D, int H, int LD, hipStream_t s);
+                    int D, int H, int LD, int dt, hipStream_t s);
 int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
-                     int H, int LD, int accumulate, hipStream_t s);
+                     int H, int LD, int accumulate, int dt, hipStream_t s);
 size_t langrew_call_ws_floats(int R, int D, int H, int LD);
 int langrew_call_forward(const float* e0, const float* eg, const float* le, const float* params, float* score, float* ws, int R,
                          int D, int H, int LD, hipStream_t s);
@@ -483,17 +483,27 @@ int r3m_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
 
 long long r3m_langrew_num_params(int D, int hidden, int lang_dim) { return langrew_num_params(D, hidden, lang_dim); }
 size_t r3m_langrew_workspace_bytes(int B, int D, int hidden, int lang_dim) { return langrew_ws_floats(B, D, hidden, lang_dim) * 4; }
-int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* ws,
-                        size_t ws_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream) {
+int r3m_langrew_forward_dt(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* ws,
+                           size_t ws_bytes, int B, int D, int hidden, int lang_dim, int dtype, r3m_stream_t stream) {
   R3M_REQUIRE(alle && feats && perm && params && scores && ws, "langrew_forward: null argument");
   R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_forward: workspace too small");
-  return langrew_forward(alle, feats, perm, params, scores, static_cast<float*>(ws), B, D, hidden, lang_dim, S(stream));
+  if (check_dt(dtype, "langrew_forward")) return 1;
+  return langrew_forward(alle, feats, perm, params, scores, static_cast<float*>(ws), B, D, hidden, lang_dim, dtype, S(stream));
+}
+int r3m_langrew_backward_dt(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* ws,
+                            size_t ws_bytes, int B, int D, int hidden, int lang_dim, int accumulate, int dtype, r3m_stream_t stream) {
+  R3M_REQUIRE(dscore && iperm && params && grads && ws, "langrew_backward: null argument");
+  R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_backward: workspace too small");
+  if (check_dt(dtype, "langrew_backward")) return 1;
+  return langrew_backward(dscore, iperm, params, grads, dalle, static_cast<float*>(ws), B, D, hidden, lang_dim, accumulate, dtype, S(stream));
+}
+int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* ws,
+                        size_t ws_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream) {
+  return r3m_langrew_forward_dt(alle, feats, perm, params, scores, ws, ws_bytes, B, D, hidden, lang_dim, DT_F32, stream);
 }
 int r3m_langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* ws,
                          size_t ws_bytes, int B, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream) {
-  R3M_REQUIRE(dscore && iperm && params && grads && ws, "langrew_backward: null argument");
-  R3M_REQUIRE(ws_bytes >= r3m_langrew_workspace_bytes(B, D, hidden, lang_dim), "langrew_backward: workspace too small");
-  return langrew_backward(dscore, iperm, params, grads, dalle, static_cast<float*>(ws), B, D, hidden, lang_dim, accumulate, S(stream));
+  return r3m_langrew_backward_dt(dscore, iperm, params, grads, dalle, ws, ws_bytes, B, D, hidden, lang_dim, accumulate, DT_F32, stream);
 }
 
 size_t r3m_langrew_call_workspace_bytes(int R, int D, int hidden, int lang_dim) { return langrew_call_ws_floats(R, D, hidden, lang_dim) * 4; }

@@ -9,6 +9,7 @@
 //   other_j = (eg, es1, es2)[j]
 // Parameter layout (flat, = state-dict order pred.{0,2,4,6,8}.{weight,bias}): W1[H][K1] b1[H] W2[H][H] b2 W3 b3 W4 b4 w5[H] b5[1]
 #include "common.h"
+#include "conv_dev.h"
 
 namespace r3m {
 
@@ -17,6 +18,8 @@ int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, 
 int conv_wgrad_launch(const float* X, const float* dY, float* dW, float* partial_ws, int N, int Hi, int Wi, int Ci, int Co, int k,
                       int stride, int pad, int accumulate, int dt, hipStream_t s);
 size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int dt);
+int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s);
+int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s);
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -29,22 +32,23 @@ __device__ __forceinline__ int lang_bframe(int q) {
 }
 
 // X[(q*B + i), :] = [ alle[src,0,:], alle[src,bf(q),:], feats[i,:] ],  src = q < 6 ? i : perm[q-6][i]
+template <class T>   // T = storage type of the MLP's tensors (float, or bf16_t for the mixed-precision head)
 __global__ __launch_bounds__(256) void lang_gather_kernel(const float* __restrict__ alle, const float* __restrict__ feats,
-                                                           const int* __restrict__ perm, float* __restrict__ X, int B, int D,
+                                                           const int* __restrict__ perm, T* __restrict__ X, int B, int D,
                                                            int LD) {
   const int row = blockIdx.x;
   const int q = row / B, i = row - q * B;
   const int src = q < 6 ? i : perm[(q - 6) * B + i];
   const int K1 = 2 * D + LD;
-  float* x = X + (long long)row * K1;
+  T* x = X + (long long)row * K1;
   const float* a = alle + ((long long)src * 5 + 0) * D;
   const float* b = alle + ((long long)src * 5 + lang_bframe(q)) * D;
   const float* l = feats + (long long)i * LD;
   for (int d = threadIdx.x * 4; d < D; d += 1024) {
-    *reinterpret_cast<f32x4*>(x + d) = ld4g(a + d);
-    *reinterpret_cast<f32x4*>(x + D + d) = ld4g(b + d);
+    st4t(x + d, ld4g(a + d));
+    st4t(x + D + d, ld4g(b + d));
   }
-  for (int d = threadIdx.x * 4; d < LD; d += 1024) *reinterpret_cast<f32x4*>(x + 2 * D + d) = ld4g(l + d);
+  for (int d = threadIdx.x * 4; d < LD; d += 1024) st4t(x + 2 * D + d, ld4g(l + d));
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -54,14 +58,15 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // score[r] = H[r,:] . w + b     (one wave per row)
-__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
+template <class T>
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const T* __restrict__ H, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ score, int rows, int K) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
   float s = 0.f;
   for (int k = lane * 4; k < K; k += 256) {
-    const f32x4 h = ld4g(H + (long long)r * K + k), ww = ld4g(w + k);
+    const f32x4 h = ld4t(H + (long long)r * K + k), ww = ld4g(w + k);
     s += h[0] * ww[0] + h[1] * ww[1] + h[2] * ww[2] + h[3] * ww[3];
   }
   s = wsum(s);
@@ -69,19 +74,20 @@ __global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__
 }
 
 // dZ[r,k] = H[r,k] > 0 ? ds[r] * w[k] : 0    (gradient entering the last ReLU)
-__global__ __launch_bounds__(256) void gemv_bwd_input_kernel(const float* __restrict__ ds, const float* __restrict__ H,
-                                                              const float* __restrict__ w, float* __restrict__ dZ,
+template <class T>
+__global__ __launch_bounds__(256) void gemv_bwd_input_kernel(const float* __restrict__ ds, const T* __restrict__ H,
+                                                              const float* __restrict__ w, T* __restrict__ dZ,
                                                               long long n4, int K4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const long long r = i / K4;
   const int k = (int)(i - r * K4) * 4;
   const float g = ds[r];
-  const f32x4 h = ld4g(H + i * 4), ww = ld4g(w + k);
+  const f32x4 h = ld4t(H + i * 4), ww = ld4g(w + k);
   f32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = h[e] > 0.f ? g * ww[e] : 0.f;
-  *reinterpret_cast<f32x4*>(dZ + i * 4) = o;
+  st4t(dZ + i * 4, o);
 }
 
 // column reductions over rows, fixed order: out[c] (+)= sum_r coef(r) * A[r,c]   (coef = ds[r] when ds != null, else 1)
@@ -93,7 +99,8 @@ static inline int colsum_slices(int rows) {
   const int s = ceil_div(rows, 64);
   return s < 1 ? 1 : (s > CS_MAX_SLICES ? CS_MAX_SLICES : s);
 }
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, const float* __restrict__ ds,
+template <class T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ A, const float* __restrict__ ds,
                                                               float* __restrict__ partial, int rows, int C, int rows_per_slice) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int r1 = r0 + rows_per_slice < rows ? r0 + rows_per_slice : rows;
   float s = 0.f;
   if (c < C)
-    for (int r = r0 + ty; r < r1; r += 4) s = fmaf(ds ? ds[r] : 1.f, A[(long long)r * C + c], s);
+    for (int r = r0 + ty; r < r1; r += 4) s = fmaf(ds ? ds[r] : 1.f, (float)A[(long long)r * C + c], s);
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && c < C) partial[(long long)blockIdx.y * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
@@ -116,9 +123,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   out[c] = accumulate ? out[c] + s : s;
 }
 // scratch: CS_MAX_SLICES * C floats
-static int launch_colsum(const float* A, const float* ds, float* out, float* scratch, int rows, int C, int accumulate, hipStream_t s) {
+template <class T>
+static int launch_colsum(const T* A, const float* ds, float* out, float* scratch, int rows, int C, int accumulate, hipStream_t s) {
   const int S = colsum_slices(rows);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(C, 64), S), dim3(256), 0, s, A, ds, scratch, rows, C, ceil_div(rows, S));
+  hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(ceil_div(C, 64), S), dim3(256), 0, s, A, ds, scratch, rows, C, ceil_div(rows, S));
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, scratch, out, S, C, accumulate);
   return check_launch("colsum");
 }
@@ -137,7 +145,8 @@ __global__ void sum_kernel(const float* __restrict__ v, float* __restrict__ out,
 }
 
 // dalle[i,f,:] += sum over every row of dX that was gathered from alle[i,f,:]   (fixed order q = 0..14)
-__global__ __launch_bounds__(256) void lang_scatter_kernel(const float* __restrict__ dX, const int* __restrict__ iperm,
+template <class T>
+__global__ __launch_bounds__(256) void lang_scatter_kernel(const T* __restrict__ dX, const int* __restrict__ iperm,
                                                             float* __restrict__ dalle, int B, int D, int LD) {
   const int i = blockIdx.x, f = blockIdx.y;
   const long long K1 = 2LL * D + LD;
@@ -152,9 +161,9 @@ __global__ __launch_bounds__(256) void lang_scatter_kernel(const float* __restri
     f32x4 g = ld4g(out + d);
 #pragma unroll
     for (int q = 0; q < 15; ++q) {
-      const float* x = dX + ((long long)q * B + rows[q]) * K1;
-      if (f == 0) g += ld4g(x + d);                        // first image of every call is e0
-      if (lang_bframe(q) == f) g += ld4g(x + D + d);       // second image
+      const T* x = dX + ((long long)q * B + rows[q]) * K1;
+      if (f == 0) g += ld4t(x + d);                        // first image of every call is e0
+      if (lang_bframe(q) == f) g += ld4t(x + D + d);       // second image
     }
     *reinterpret_cast<f32x4*>(out + d) = g;
   }
@@ -165,7 +174,7 @@ struct LangDims {
   long long w[5], b[5];      // parameter offsets (floats)
   long long n_params;
   // workspace offsets (floats)
-  long long X, Hh[4], dA, dB, Wt, wgp, cs, total;
+  long long X, Hh[4], dA, dB, Wt, wgp, cs, w16, total;
 };
 
 // R = rows of the MLP input: 15 B for the batched step (B clips), or the row count of ONE get_reward call (B = 0)
@@ -186,11 +195,15 @@ static LangDims lang_dims_rows(int R, int B, int D, int H, int LD) {
   d.dA = take((long long)d.R * (d.K1 > H ? d.K1 : H));
   d.dB = take((long long)d.R * H);
   d.Wt = take((long long)H * d.K1);
-  long long wg = conv_wgrad_ws_floats(d.R, 1, 1, d.K1, H, 1, 1, 0, DT_F32);
-  const long long wg2 = conv_wgrad_ws_floats(d.R, 1, 1, H, H, 1, 1, 0, DT_F32);
-  if (wg2 > wg) wg = wg2;
+  long long wg = 0;
+  for (int dt : {DT_F32, DT_BF16})
+    for (int K : {d.K1, H}) {
+      const long long v = (long long)conv_wgrad_ws_floats(d.R, 1, 1, K, H, 1, 1, 0, dt);
+      if (v > wg) wg = v;
+    }
   d.wgp = take(wg);
   d.cs = take((long long)CS_MAX_SLICES * H);
+  d.w16 = take((d.n_params + 1) / 2);       // bf16 image of the weights (mixed-precision head)
   d.total = ws;
   return d;
 }
@@ -201,35 +214,83 @@ long long langrew_num_params(int D, int H, int LD) { return lang_dims(1, D, H, L
 size_t langrew_call_ws_floats(int R, int D, int H, int LD) { return (size_t)lang_dims_rows(R, 0, D, H, LD).total; }
 size_t langrew_ws_floats(int B, int D, int H, int LD) { return (size_t)lang_dims(B, D, H, LD).total; }
 
-static int check_dims(const LangDims& d) {
+static int check_dims(const LangDims& d, int dt = DT_F32) {
   R3M_REQUIRE(d.D % 32 == 0 && d.LD % 32 == 0 && d.H % 64 == 0, "langrew: D=%d, lang_dim=%d must be multiples of 32, hidden=%d of 64",
               d.D, d.LD, d.H);
+  R3M_REQUIRE(dt == DT_F32 || dt == DT_BF16, "langrew: unknown dtype %d", dt);
+  R3M_REQUIRE(dt == DT_F32 || d.LD % 64 == 0, "langrew(bf16): lang_dim=%d must be a multiple of 64", d.LD);
   return 0;
 }
 
+// ---- mixed-precision head (dt == DT_BF16; R3M(precision="bf16"): what torch.autocast(bfloat16) around the reference's
+// get_reward calls would do) ----------------------------------------------------------------------------------------------
+// X, the hidden activations and their gradients are stored bf16 (same workspace slots, half used); every Linear runs on the
+// bf16 GEMM kernels with fp32 accumulation (forward: bf16 image of the fp32 master weights made per call; dgrad: bf16
+// transposed image; weight gradients: bf16 operands -> fp32 gradients); biases, the final Linear(H -> 1), the scores, all
+// parameter gradients and dalle stay fp32. The bf16 GEMM epilogues in use are the plain stores, so bias + ReLU and the ReLU
+// mask of the backward are two small in-place passes over the [R, H] tensor (3840 x 1024: ~4 us each).
+__global__ __launch_bounds__(256) void bias_relu16_kernel(bf16_t* __restrict__ Z, const float* __restrict__ bias, long long n8, int C8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)(i % C8) * 8;
+  const bf16x8 z = *reinterpret_cast<const bf16x8*>(Z + i * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf((float)z[e] + bias[c + e], 0.f);
+  *reinterpret_cast<bf16x8*>(Z + i * 8) = o;
+}
+// dA[r, k] = H[r, k] > 0 ? dA[r, k] : 0
+__global__ __launch_bounds__(256) void relu_mask16_kernel(bf16_t* __restrict__ dA, const bf16_t* __restrict__ Hh, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + i * 8), h = *reinterpret_cast<const bf16x8*>(Hh + i * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (float)h[e] > 0.f ? g[e] : (bf16_t)0.f;
+  *reinterpret_cast<bf16x8*>(dA + i * 8) = o;
+}
+
+static inline bf16_t* as16(float* p) { return reinterpret_cast<bf16_t*>(p); }
+
 // the MLP proper on the rows staged at ws + d.X: 4 x (Linear + ReLU) on the gather-GEMM, Linear(H -> 1) as a GEMV
-static int mlp_forward(const LangDims& d, const float* params, float* scores, float* ws, hipStream_t s) {
+static int mlp_forward(const LangDims& d, const float* params, float* scores, float* ws, int dt, hipStream_t s) {
   const int H = d.H;
   const float* in = ws + d.X;
   int K = d.K1;
   for (int l = 0; l < 4; ++l) {
-    if (int e = conv_forward_launch(in, params + d.w[l], ws + d.Hh[l], nullptr, params + d.b[l], d.R, 1, 1, K, H, 1, 1, 0,
-                                    EPI_BIAS | EPI_RELU, DT_F32, s))
+    if (dt == DT_BF16) {
+      bf16_t* w16 = as16(ws + d.w16) + d.w[l];
+      if (int e = launch_convert_bf16(params + d.w[l], w16, (long long)K * H, s)) return e;
+      if (int e = conv_forward_launch(in, reinterpret_cast<const float*>(w16), ws + d.Hh[l], nullptr, nullptr, d.R, 1, 1, K, H, 1, 1, 0, 0,
+                                      DT_BF16, s))
+        return e;
+      const long long n8 = (long long)d.R * H / 8;
+      hipLaunchKernelGGL(bias_relu16_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, s, as16(ws + d.Hh[l]), params + d.b[l], n8, H / 8);
+      if (int e = check_launch("lang_bias_relu16")) return e;
+    } else if (int e = conv_forward_launch(in, params + d.w[l], ws + d.Hh[l], nullptr, params + d.b[l], d.R, 1, 1, K, H, 1, 1, 0,
+                                           EPI_BIAS | EPI_RELU, DT_F32, s))
       return e;
     in = ws + d.Hh[l];
     K = H;
   }
-  hipLaunchKernelGGL(gemv_fwd_kernel, dim3(ceil_div(d.R, 4)), dim3(256), 0, s, in, params + d.w[4], params + d.b[4], scores, d.R, H);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((gemv_fwd_kernel<bf16_t>), dim3(ceil_div(d.R, 4)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(in),
+                       params + d.w[4], params + d.b[4], scores, d.R, H);
+  else
+    hipLaunchKernelGGL((gemv_fwd_kernel<float>), dim3(ceil_div(d.R, 4)), dim3(256), 0, s, in, params + d.w[4], params + d.b[4], scores, d.R, H);
   return check_launch("gemv_fwd");
 }
 
 int langrew_forward(const float* alle, const float* feats, const int* perm, const float* params, float* scores, float* ws, int B,
-                    int D, int H, int LD, hipStream_t s) {
+                    int D, int H, int LD, int dt, hipStream_t s) {
   const LangDims d = lang_dims(B, D, H, LD);
-  if (int e = check_dims(d)) return e;
-  hipLaunchKernelGGL(lang_gather_kernel, dim3(d.R), dim3(256), 0, s, alle, feats, perm, ws + d.X, B, D, LD);
+  if (int e = check_dims(d, dt)) return e;
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((lang_gather_kernel<bf16_t>), dim3(d.R), dim3(256), 0, s, alle, feats, perm, as16(ws + d.X), B, D, LD);
+  else
+    hipLaunchKernelGGL((lang_gather_kernel<float>), dim3(d.R), dim3(256), 0, s, alle, feats, perm, ws + d.X, B, D, LD);
   if (int e = check_launch("lang_gather")) return e;
-  return mlp_forward(d, params, scores, ws, s);
+  return mlp_forward(d, params, scores, ws, dt, s);
 }
 
 int launch_transpose_w(const float* W, float* Wt, int Co, int T, int Ci, hipStream_t s);
@@ -239,31 +300,50 @@ int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* 
 // Needs the workspace left by the forward (X and the four hidden activations).
 // dscore [R] -> parameter gradients (= or +=); returns the buffer holding dX [R, K1] (inside ws) through *dx_out
 static int mlp_backward(const LangDims& d, const float* dscore, const float* params, float* grads, float* ws, int accumulate,
-                        float** dx_out, hipStream_t s) {
+                        float** dx_out, int dt, hipStream_t s) {
   const int H = d.H;
+  const bool h16 = dt == DT_BF16;
   float* dA = ws + d.dA;
   float* dB = ws + d.dB;
   float* Wt = ws + d.Wt;
   float* wgp = ws + d.wgp;
   const float* H4 = ws + d.Hh[3];
   // last Linear(H -> 1)
-  if (int e = launch_colsum(H4, dscore, grads + d.w[4], ws + d.cs, d.R, H, accumulate, s)) return e;
+  if (int e = h16 ? launch_colsum(reinterpret_cast<const bf16_t*>(H4), dscore, grads + d.w[4], ws + d.cs, d.R, H, accumulate, s)
+                  : launch_colsum(H4, dscore, grads + d.w[4], ws + d.cs, d.R, H, accumulate, s))
+    return e;
   hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, dscore, grads + d.b[4], d.R, accumulate);
   const long long n4 = (long long)d.R * H / 4;
-  hipLaunchKernelGGL(gemv_bwd_input_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, s, dscore, H4, params + d.w[4], dA, n4, H / 4);
+  if (h16)
+    hipLaunchKernelGGL((gemv_bwd_input_kernel<bf16_t>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, dscore, reinterpret_cast<const bf16_t*>(H4),
+                       params + d.w[4], as16(dA), n4, H / 4);
+  else
+    hipLaunchKernelGGL((gemv_bwd_input_kernel<float>), dim3(ceil_div(n4, 256)), dim3(256), 0, s, dscore, H4, params + d.w[4], dA, n4, H / 4);
   if (int e = check_launch("lang_head_bwd")) return e;
-  // hidden Linear layers 4..1:  dZ_l -> dW_l, db_l, dZ_{l-1} (ReLU mask of H_{l-1} fused into the dgrad epilogue).
-  // Ping-pong dA -> dB -> dA -> dB -> dA: the last product, dX [15B, K1], lands in dA (the buffer sized for K1).
+  // hidden Linear layers 4..1:  dZ_l -> dW_l, db_l, dZ_{l-1} (ReLU mask of H_{l-1}: fused into the fp32 dgrad epilogue, a separate
+  // in-place pass for bf16). Ping-pong dA -> dB -> dA -> dB -> dA: the last product, dX [15B, K1], lands in dA (sized for K1).
   float* dz = dA;
   float* nxt = dB;
   for (int l = 3; l >= 0; --l) {
     const float* in = l == 0 ? ws + d.X : ws + d.Hh[l - 1];
     const int K = l == 0 ? d.K1 : H;
-    if (int e = conv_wgrad_launch(in, dz, grads + d.w[l], wgp, d.R, 1, 1, K, H, 1, 1, 0, accumulate, DT_F32, s)) return e;
-    if (int e = launch_colsum(dz, nullptr, grads + d.b[l], ws + d.cs, d.R, H, accumulate, s)) return e;
-    if (int e = launch_transpose_w(params + d.w[l], Wt, H, 1, K, s)) return e;
-    if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, nullptr, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, DT_F32, s))
+    if (int e = conv_wgrad_launch(in, dz, grads + d.w[l], wgp, d.R, 1, 1, K, H, 1, 1, 0, accumulate, dt, s)) return e;
+    if (int e = h16 ? launch_colsum(reinterpret_cast<const bf16_t*>(dz), nullptr, grads + d.b[l], ws + d.cs, d.R, H, accumulate, s)
+                    : launch_colsum(dz, nullptr, grads + d.b[l], ws + d.cs, d.R, H, accumulate, s))
       return e;
+    if (h16) {
+      if (int e = launch_transpose_w_bf16(params + d.w[l], Wt, H, 1, K, s)) return e;
+      if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, nullptr, nullptr, d.R, 1, 1, K, H, 1, 1, 0, 0, DT_BF16, s)) return e;
+      if (l > 0) {
+        const long long n8 = (long long)d.R * H / 8;
+        hipLaunchKernelGGL(relu_mask16_kernel, dim3(ceil_div(n8, 256)), dim3(256), 0, s, as16(nxt), reinterpret_cast<const bf16_t*>(in), n8);
+        if (int e = check_launch("lang_relu_mask16")) return e;
+      }
+    } else {
+      if (int e = launch_transpose_w(params + d.w[l], Wt, H, 1, K, s)) return e;
+      if (int e = conv_dgrad_launch(dz, Wt, nxt, nullptr, l == 0 ? nullptr : in, nullptr, d.R, 1, 1, K, H, 1, 1, 0, l == 0 ? 0 : EPI_MASK_OUT, DT_F32, s))
+        return e;
+    }
     float* t = dz; dz = nxt; nxt = t;
   }
   *dx_out = dz;   // dX [R, K1]
@@ -271,13 +351,16 @@ static int mlp_backward(const LangDims& d, const float* dscore, const float* par
 }
 
 int langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, float* ws, int B, int D,
-                     int H, int LD, int accumulate, hipStream_t s) {
+                     int H, int LD, int accumulate, int dt, hipStream_t s) {
   const LangDims d = lang_dims(B, D, H, LD);
-  if (int e = check_dims(d)) return e;
+  if (int e = check_dims(d, dt)) return e;
   float* dz = nullptr;
-  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, s)) return e;
+  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, dt, s)) return e;
   if (dalle) {
-    hipLaunchKernelGGL(lang_scatter_kernel, dim3(B, 5), dim3(256), 0, s, dz, iperm, dalle, B, D, LD);
+    if (dt == DT_BF16)
+      hipLaunchKernelGGL((lang_scatter_kernel<bf16_t>), dim3(B, 5), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(dz), iperm, dalle, B, D, LD);
+    else
+      hipLaunchKernelGGL((lang_scatter_kernel<float>), dim3(B, 5), dim3(256), 0, s, dz, iperm, dalle, B, D, LD);
     if (int e = check_launch("lang_scatter")) return e;
   }
   return 0;
@@ -315,7 +398,7 @@ int langrew_call_forward(const float* e0, const float* eg, const float* le, cons
   if (int e = check_dims(d)) return e;
   hipLaunchKernelGGL(lang_concat_kernel, dim3(R), dim3(256), 0, s, e0, eg, le, ws + d.X, D, LD);
   if (int e = check_launch("lang_concat")) return e;
-  return mlp_forward(d, params, score, ws, s);
+  return mlp_forward(d, params, score, ws, DT_F32, s);
 }
 
 int langrew_call_backward(const float* dscore, const float* params, float* grads, float* de0, float* deg, float* dle, float* ws,
@@ -323,7 +406,7 @@ int langrew_call_backward(const float* dscore, const float* params, float* grads
   const LangDims d = lang_dims_rows(R, 0, D, H, LD);
   if (int e = check_dims(d)) return e;
   float* dz = nullptr;
-  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, s)) return e;
+  if (int e = mlp_backward(d, dscore, params, grads, ws, accumulate, &dz, DT_F32, s)) return e;
   if (de0 || deg || dle) {
     hipLaunchKernelGGL(lang_split_kernel, dim3(R), dim3(256), 0, s, dz, de0, deg, dle, D, LD);
     if (int e = check_launch("lang_split")) return e;

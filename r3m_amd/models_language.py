@@ -124,10 +124,11 @@ class _BatchedRewardFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=alle.device)
         scores = torch.empty((15, B), dtype=torch.float32, device=alle.device)
         with _lib.on(alle):
-            _lib.check(L.r3m_langrew_forward(alle.data_ptr(), feats.data_ptr(), perm.data_ptr(), module.flat_params().data_ptr(),
-                                             scores.data_ptr(), ws.data_ptr(), ws_bytes, B, D, module.hidden_dim, module.lang_dim,
-                                             _lib.stream_ptr(alle.device)), "langrew_forward")
-        ctx.module, ctx.ws, ctx.ws_bytes, ctx.dims = module, ws, ws_bytes, (B, D)
+            dt = 1 if getattr(module, "precision", "fp32") == "bf16" else 0
+            _lib.check(L.r3m_langrew_forward_dt(alle.data_ptr(), feats.data_ptr(), perm.data_ptr(), module.flat_params().data_ptr(),
+                                                scores.data_ptr(), ws.data_ptr(), ws_bytes, B, D, module.hidden_dim, module.lang_dim,
+                                                dt, _lib.stream_ptr(alle.device)), "langrew_forward")
+        ctx.module, ctx.ws, ctx.ws_bytes, ctx.dims, ctx.dt = module, ws, ws_bytes, (B, D), dt
         ctx.save_for_backward(perm)
         return scores
 
@@ -143,9 +144,9 @@ class _BatchedRewardFn(torch.autograd.Function):
         accumulate = 0 if module._grad_fresh else 1
         dscores = dscores.contiguous()
         with _lib.on(dscores):
-            _lib.check(L.r3m_langrew_backward(dscores.data_ptr(), iperm.data_ptr(), module.flat_params().data_ptr(),
-                                              g.data_ptr(), dalle.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes, B, D, module.hidden_dim,
-                                              module.lang_dim, accumulate, _lib.stream_ptr(dscores.device)), "langrew_backward")
+            _lib.check(L.r3m_langrew_backward_dt(dscores.data_ptr(), iperm.data_ptr(), module.flat_params().data_ptr(),
+                                                 g.data_ptr(), dalle.data_ptr(), ctx.ws.data_ptr(), ctx.ws_bytes, B, D, module.hidden_dim,
+                                                 module.lang_dim, accumulate, ctx.dt, _lib.stream_ptr(dscores.device)), "langrew_backward")
         module._grad_fresh = False
         module._has_grads = True
         ctx.ws = None
@@ -199,8 +200,14 @@ class _RewardCallFn(torch.autograd.Function):
 
 
 class LanguageReward(nn.Module):
-    def __init__(self, ltype, im_dim, hidden_dim, lang_dim, simfunc=None):
+    def __init__(self, ltype, im_dim, hidden_dim, lang_dim, simfunc=None, precision="fp32"):
         super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"LanguageReward: precision {precision!r} (fp32 or bf16)")
+        # "bf16": the batched training pass stores the MLP's activations bf16 and runs its Linears on the bf16 GEMM kernels (fp32
+        # accumulation, fp32 master weights / gradients) — what autocast(bfloat16) around the reference's get_reward calls does.
+        # The single-call form (forward / R3M.get_reward) stays fp32.
+        self.precision = precision
         self.ltype = ltype
         self.sim = simfunc
         self.sigm = nn.Sigmoid()

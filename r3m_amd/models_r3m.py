@@ -62,7 +62,7 @@ class R3M(nn.Module):
         if self.langweight > 0.0:
             from .models_language import LangEncoder, LanguageReward
             self.lang_enc = LangEncoder(self.device, 0, 0)
-            self.lang_rew = LanguageReward(None, self.outdim, hidden_dim, self.lang_enc.lang_size, simfunc=self.sim)
+            self.lang_rew = LanguageReward(None, self.outdim, hidden_dim, self.lang_enc.lang_size, simfunc=self.sim, precision=precision)
             owners.append(self.lang_rew)
 
         self.encoder_opt = FusedAdam(owners, lr=lr)

@@ -346,3 +346,61 @@ def test_step_with_sentence_strings_runs_the_text_model_once(hip):
     assert res["strings"].keys() == res["features"].keys()
     for k in res["strings"]:
         assert res["strings"][k] == res["features"][k], k
+
+
+@pytest.mark.parametrize("B,D", [(3, 512), (16, 2048)])
+def test_bf16_head_follows_fp32_head_and_its_own_rounding_model(hip, B, D):
+    """LanguageReward(precision="bf16") (r3m_langrew_*_dt with R3M_DT_BF16): the batched pass with bf16 storage of the MLP's tensors and
+    bf16 GEMM operands. Checker 1 = the fp32 head on the same inputs (scores and gradients follow it to bf16 accuracy). Checker 2 = a
+    float64 torch MLP with a bf16 rounding exactly where the kernel stores bf16 (input rows, weights, every hidden activation):
+    the forward must match THAT to accumulation accuracy — a wrong layout / missing bias / wrong mask cannot hide in bf16 noise."""
+    from oracle import detgen
+    from r3m_amd.models_language import LanguageReward
+    H, LD = 1024, 768
+    torch.manual_seed(11)
+    perm = torch.stack([torch.randperm(B) for _ in range(9)]).to(torch.int32).to(DEV)
+    alle0 = torch.from_numpy(detgen.uniform("alle16", (B, 5, D), -1.0, 1.0))
+    feats = torch.from_numpy(detgen.uniform("langfeat16", (B, LD), -0.6, 0.6)).to(DEV)
+    wts = torch.from_numpy(detgen.uniform("dscore16", (15, B), -1.0, 1.0)).to(DEV)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        rew = LanguageReward(None, D, H, LD, precision=prec)
+        rew.load_state_dict(_lang_state(rew))
+        rew = rew.to(DEV)
+        alle = alle0.clone().to(DEV).requires_grad_(True)
+        scores = rew.batched_scores(alle, feats, perm)
+        rew.mark_grads_stale()
+        (scores * wts).sum().backward()
+        res[prec] = (scores.detach().double().cpu(), alle.grad.double().cpu(), rew.flat_grads().double().cpu().clone(), rew)
+
+    def cos(a, b):
+        return float((a * b).sum() / (a.norm() * b.norm()))
+    s32, da32, g32, rew32 = res["fp32"]
+    s16, da16, g16, _ = res["bf16"]
+    print(f"bf16 head B={B} D={D}: scores max|d| {float((s16 - s32).abs().max()):.3e} (max|s| {float(s32.abs().max()):.3f}); "
+          f"cos dalle {cos(da16, da32):.6f}, cos param grads {cos(g16, g32):.6f}")
+    assert float((s16 - s32).abs().max()) <= 2e-2 * max(1.0, float(s32.abs().max()))
+    assert cos(da16, da32) >= 0.99 and cos(g16, g32) >= 0.99
+
+    # checker 2: float64 MLP with the kernel's rounding points (straight-through in the backward pass)
+    def r16(t):
+        return t + (t.to(torch.bfloat16).to(torch.float64) - t).detach()
+    sd = {k: v.double().cpu().clone().requires_grad_(True) for k, v in rew32.state_dict().items()}
+    a64 = alle0.double().clone().requires_grad_(True)
+    bframe = [1, 3, 4, 0, 2, 3] + [1, 3, 4] * 3
+    rows = []
+    for q in range(15):
+        src = torch.arange(B) if q < 6 else perm[q - 6].cpu().long()
+        rows.append(torch.cat([a64[src, 0], a64[src, bframe[q]], feats.cpu().double()], dim=1))
+    x = r16(torch.cat(rows, dim=0))
+    for li in (0, 2, 4, 6):
+        x = r16(torch.relu(r16(x @ r16(sd[f"pred.{li}.weight"]).T) + sd[f"pred.{li}.bias"]))
+    s_model = (x @ sd["pred.8.weight"].T + sd["pred.8.bias"]).reshape(15, B)
+    (s_model * wts.cpu().double()).sum().backward()
+    err = float((s16 - s_model.detach()).abs().max())
+    g_model = torch.cat([sd[f"pred.{li}.{pn}"].grad.reshape(-1) for li in (0, 2, 4, 6, 8) for pn in ("weight", "bias")])
+    n = g_model.numel()
+    print(f"bf16 head vs its float64 rounding model: scores max|d| {err:.3e}; cos dalle {cos(da16, a64.grad):.6f}, cos param grads "
+          f"{cos(g16[:n], g_model):.6f} (fp32 head vs the same model: {cos(da32, a64.grad):.6f} / {cos(g32[:n], g_model):.6f})")
+    assert err <= 2e-3 * max(1.0, float(s_model.detach().abs().max()))
+    assert cos(da16, a64.grad) >= 0.999 and cos(g16[:n], g_model) >= 0.999
