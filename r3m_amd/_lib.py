@@ -139,6 +139,29 @@ def check(rc, what=""):
         raise RuntimeError(f"r3m_hip {what} failed (code {rc}): {last_error()}")
 
 
+_pinned = {}
+
+
+def upload_small(t, device, dtype=None):
+    """Host tensor -> `device` without stalling the host: a copy from PAGEABLE memory is stream-ordered AND blocks the calling
+    thread on ROCm, i.e. the host waits for everything queued before it (the previous step's backward when it sits at the top of a
+    step) and cannot queue ahead. Small per-step tensors (crop boxes, permutations) go through a ring of four pinned staging
+    buffers per (shape, dtype) instead; a buffer is reused four uploads later, by when its copy has long run (Trainer.update
+    waits for the step's metrics, which are queued behind that step's uploads)."""
+    import torch
+    if t.is_cuda or torch.device(device).type != "cuda":
+        return t.to(device=device, dtype=dtype or t.dtype)
+    src = t.to(dtype or t.dtype).contiguous()
+    key = (tuple(src.shape), src.dtype)
+    ring = _pinned.setdefault(key, [[], 0])
+    if len(ring[0]) < 4:
+        ring[0].append(torch.empty(src.shape, dtype=src.dtype, pin_memory=True))
+    buf = ring[0][ring[1] % len(ring[0])]
+    ring[1] += 1
+    buf.copy_(src)
+    return buf.to(device, non_blocking=True)
+
+
 def stream_ptr(device=None):
     """HIP stream handle torch is currently using on `device` (a torch.device / index; None = the current device)."""
     import torch

@@ -86,7 +86,7 @@ def crop_resize(frames, boxes, frames_per_box, out_hw=(224, 224)):
         frames = frames.float()
     frames = frames.contiguous()
     N, C, H, W = frames.shape
-    boxes = boxes.to(device=frames.device, dtype=torch.int32).contiguous()
+    boxes = _lib.upload_small(boxes, frames.device, torch.int32).contiguous()
     assert boxes.shape[0] * frames_per_box == N
     out = torch.empty((N, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=frames.device)
     with _lib.on(frames):
@@ -110,7 +110,7 @@ class CroppedClips:
             raw = raw.float()
         lead = raw.shape[:-3]
         self.raw = raw.reshape(-1, *raw.shape[-3:]).contiguous()                       # [N,3,H,W]
-        self.boxes = boxes.to(device=raw.device, dtype=torch.int32).contiguous()
+        self.boxes = _lib.upload_small(boxes, raw.device, torch.int32).contiguous()
         self.frames_per_box = int(frames_per_box)
         assert self.boxes.shape[0] * self.frames_per_box == self.raw.shape[0] and self.raw.shape[1] == 3
         self.out_hw = tuple(out_hw)

@@ -14,7 +14,7 @@ import time
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 epsilon = 1e-8
 
@@ -50,7 +50,7 @@ class Trainer:
         tcn_perm = None
         if core.tcnweight > 0:
             tcn_perm = torch.stack([torch.randperm(bs) for _ in range(2 * core.num_negatives)]).to(torch.int32)
-            tcn_perm = tcn_perm.to(alle.device, non_blocking=True)
+            tcn_perm = _lib.upload_small(tcn_perm, alle.device)      # pinned staging: a pageable copy would stall the host here
 
         if core.langweight > 0:
             # b_lang: list[str] as in the reference, or precomputed frozen features [B,768] / (features, mask[B])
@@ -58,7 +58,7 @@ class Trainer:
             if isinstance(b_lang, (tuple, list)) and len(b_lang) == 2 and torch.is_tensor(b_lang[0]):
                 b_lang, lang_mask = b_lang
             feats = core.lang_enc(b_lang).to(alle.device)
-            scores = core.lang_rew.batched_scores(alle, feats, lang_perm.to(alle.device))
+            scores = core.lang_rew.batched_scores(alle, feats, _lib.upload_small(lang_perm, alle.device, torch.int32))
             if lang_mask is not None:
                 mask = lang_mask.to(device=alle.device, dtype=torch.float32)
             elif torch.is_tensor(b_lang):
