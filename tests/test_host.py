@@ -250,3 +250,13 @@ def test_box_sampler_matches_the_scalar_get_params_loop():
         assert a.dtype == torch.int32 and tuple(a.shape) == (n, 4) and torch.equal(a, b), (n, H, W)
         top, left, h, w = a.unbind(1)
         assert (top >= 0).all() and (left >= 0).all() and (top + h <= H).all() and (left + w <= W).all()
+
+
+def test_upload_small_keeps_values_and_dtype_on_a_cpu_target():
+    """_lib.upload_small (pinned staging for the per-step crop boxes / permutations) degrades to a plain conversion when the
+    target is not a GPU; values and the requested dtype are kept (the GPU path is exercised by every Trainer.update test)."""
+    from r3m_amd import _lib
+    t = torch.arange(12, dtype=torch.int64).reshape(3, 4)
+    out = _lib.upload_small(t, "cpu", torch.int32)
+    assert out.dtype == torch.int32 and torch.equal(out.to(torch.int64), t)
+    assert torch.equal(_lib.upload_small(t, torch.device("cpu")), t)
