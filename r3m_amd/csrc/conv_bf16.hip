@@ -605,7 +605,9 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
 // in x), and each tap still stages its own exactly-masked X rows (no register masks, any width / stride). Per tap this is 2/3 of
 // the L2 -> LDS bytes (the bf16 128 x 128 tile needs ~39 TB/s of that path at the matrix peak; the chip delivers ~17), 2/3 of
 // the DMA instructions and 2/3 of the LDS fragment reads of the per-tap form.
-template <int BMt, int BNt, int BK = 64, int NT = 1>   // BK = rows per K step: 64, or 32 (half the LDS: more blocks per CU)
+// FAST = 1: the launcher has checked that one K step advances a row by less than one frame ((BK / Wo + 1) <= Ho — every layer of
+// the networks here), so the division form of the coordinate walk is not even compiled in (registers, code size).
+template <int BMt, int BNt, int BK = 64, int NT = 1, int FAST = 0>   // BK = rows per K step: 64, or 32 (half the LDS: more blocks per CU)
 __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const WgradParams p) {
   static_assert(BK == 64 || BK == 32, "K step of 64 or 32 rows");
   static_assert(NT == 1 || NT == 3, "one tap, or the three taps of a kernel row");
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
   for (int j = 0; j < AJ; ++j) a_voff[j] = (unsigned)((wave * WR + j * A_RPI + a_k) * p.Co * 2) + a_chan;
 
   const int q64 = BK / p.Wo, r64 = BK - q64 * p.Wo;          // (oy, ox) advance of one K step
-  const bool fast_adv = (q64 + 1) <= p.Ho;
+  const bool fast_adv = FAST || (q64 + 1) <= p.Ho;
   const long long img = (long long)p.Hi * p.Wi * p.Ci * 2;
   const unsigned imgb = (unsigned)img;
   const int n0 = ms / hw;                                     // 3x3 / strided: offsets are relative to the split's first frame
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
           const bool in = rowok && ((unsigned)(ix0 + t) < (unsigned)p.Wi);
           dma(b_base, b_left, lb + t * B_TILE, in ? off0 + (unsigned)(t * pixb) : BUF_OOB);
         }
-        if (fast_adv) {
+        if (FAST || fast_adv) {
           int x = xs[j] + adv_xs, y = ys[j] + adv_ys, ps = pos[j] + adv_pos;
           const bool cx = x >= xs_wrap;
           x = cx ? x - xs_wrap : x;
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
           ps = cy ? ps - wrapy_pos : ps;
           b_off[j] = cy ? b_off[j] + imgb : b_off[j];
           xs[j] = x; ys[j] = y; pos[j] = ps;
-        } else {
+        } else if constexpr (!FAST) {
           b_m[j] += BK;
           const int n = b_m[j] / hw;
           const int rem = b_m[j] - n * hw;
@@ -1102,7 +1104,8 @@ int launch_wgrad_bf16(const WgradParams& p0, int splitK, hipStream_t s) {
   const bool bk32 = bk == 32 || (bk != 64 && wide);
   if (wg16_rows(p.KW, wide)) {   // 3-wide kernels on the 128 x 128 tile: one block = the three taps of a kernel row
     p.gx = tilesM * p.tilesN * p.KH;
-    hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32, 3>), dim3(p.gx * splitK), dim3(256), 0, s, p);
+    if ((32 / p.Wo + 1) <= p.Ho) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32, 3, 1>), dim3(p.gx * splitK), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 32, 3>), dim3(p.gx * splitK), dim3(256), 0, s, p);
     prof_bytes(2.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci) + 4.0 * (double)splitK * p.Co * T * p.Ci);
     prof_end(s);
     return check_launch("wgrad_bf16 (kernel rows)");
