@@ -611,6 +611,14 @@ template <int BMt, int BNt, int BK = 64, int NT = 1, int FAST = 0>   // BK = row
 __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const WgradParams p) {
   static_assert(BK == 64 || BK == 32, "K step of 64 or 32 rows");
   static_assert(NT == 1 || NT == 3, "one tap, or the three taps of a kernel row");
+  // compile-time where the launcher's choice is fixed: a kernel-row block (NT = 3) never has 1x1 "simple" rows, and the
+  // interleaved DMA issue is a probe-build switch only (shipped builds issue all pieces right after the barrier)
+  const bool simple_rows = NT == 1 && p.simple_rows;
+#ifdef R3M_PROBES
+  const bool interleave = p.interleave != 0;
+#else
+  constexpr bool interleave = false;
+#endif
   constexpr int WR = BK / 4;                                   // k rows staged per wave per stage
   constexpr int TM = BMt / 64, TN = BNt / 64;
   constexpr int A_ROWB = BMt * 2, B_ROWB = BNt * 2;            // bytes per k row
@@ -669,10 +677,10 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
   const long long img = (long long)p.Hi * p.Wi * p.Ci * 2;
   const unsigned imgb = (unsigned)img;
   const int n0 = ms / hw;                                     // 3x3 / strided: offsets are relative to the split's first frame
-  const char* b_base = p.simple_rows ? Xb + (long long)ms * p.Ci * 2 : Xb + (long long)n0 * img;
+  const char* b_base = simple_rows ? Xb + (long long)ms * p.Ci * 2 : Xb + (long long)n0 * img;
   int b_left;
   {
-    const long long rest = p.simple_rows ? (long long)(me - ms) * p.Ci * 2 : (long long)(p.N - n0) * img;
+    const long long rest = simple_rows ? (long long)(me - ms) * p.Ci * 2 : (long long)(p.N - n0) * img;
     b_left = rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB;
   }
   const int b_stepb = BK * p.Ci * 2;
@@ -695,7 +703,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
   for (int j = 0; j < BJ; ++j) {
     b_m[j] = ms + wave * WR + j * B_RPI + b_k;
     ys[j] = 0; xs[j] = 0; pos[j] = 0;
-    if (p.simple_rows) {
+    if (simple_rows) {
       b_off[j] = (unsigned)((wave * WR + j * B_RPI + b_k) * p.Ci * 2) + b_chan;
     } else {
       const int n = b_m[j] / hw;
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
     } else {
       constexpr int j = pc - AJ;
       unsigned char* lb = smem + stage * STAGE + BK * A_ROWB + (wave * WR + j * B_RPI) * B_ROWB;
-      if (p.simple_rows) {
+      if (simple_rows) {
         dma(b_base, b_left, lb, b_off[j]);
       } else {
         const int iy = ys[j] + kh_p, ix0 = xs[j] + kw_p;
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
     if constexpr (pc == NP - 1) {             // after the last piece of a K step: the linear descriptors move on (scalar unit)
       a_base += a_stepb;
       a_left = a_left > a_stepb ? a_left - a_stepb : 0;
-      if (p.simple_rows) {
+      if (simple_rows) {
         b_base += b_stepb;
         b_left = b_left > b_stepb ? b_left - b_stepb : 0;
       }
@@ -800,13 +808,13 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : 1) void wgrad_bf16_kernel(const 
 
   auto mfma_stage = [&](const unsigned char* st, int dma_stage) __attribute__((always_inline)) {
     // the next K step's DMA: all pieces right after the barrier (p.interleave = 1: spread between the MFMA groups instead)
-    if (dma_stage >= 0 && !p.interleave) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(dma_stage, pc); });
+    if (dma_stage >= 0 && !interleave) static_for<NP>([&](auto pc) __attribute__((always_inline)) { issue_piece(dma_stage, pc); });
     static_for<BK / 16>([&](auto s_c) __attribute__((always_inline)) {
       constexpr int sidx = decltype(s_c)::value;
       bf16x8 a[TM];
 #pragma unroll
       for (int t = 0; t < TM; ++t) a[t] = frag(st + fa_off[t], A_ROWB, sidx);
-      if (dma_stage >= 0 && p.interleave) {
+      if (dma_stage >= 0 && interleave) {
         constexpr int P0 = sidx * NP / (BK / 16), P1 = (sidx + 1) * NP / (BK / 16);
         static_for<P1 - P0>([&](auto q_c) __attribute__((always_inline)) {
           issue_piece(dma_stage, std::integral_constant<int, P0 + decltype(q_c)::value>{});
