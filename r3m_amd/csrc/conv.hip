@@ -1232,6 +1232,7 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
   constexpr int STAGE = BK * BMt + NT * B_TILE;
   __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
 
+  const bool simple_rows = NT == 1 && p.simple_rows;   // a kernel-row block (NT = 3) never has 1x1 "simple" rows: resolved at compile time
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WIDE ? 0 : (wave_s >> 1), wn = WIDE ? wave_s : (wave_s & 1);
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
   const unsigned imgb = (unsigned)(img * 4);
   const int pixb = p.Ci * 4;       // bytes between the X rows of neighbouring taps (one pixel)
   const int kh_p = kh - p.pad, kw_p = kw0 - p.pad;
-  if (p.simple_rows) {
+  if (simple_rows) {
     b_base = p.X + (long long)ms * p.Ci + ci0;
     b_left = (int)(((long long)(me - ms) * p.Ci - ci0) * 4);
 #pragma unroll
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
     } else {
       constexpr int j = pc - AJ;
       float* lb = smem + stage * STAGE + BK * BMt + wave_s * WR * BNt + j * B_RPI * BNt;
-      if (p.simple_rows) {
+      if (simple_rows) {
         buf_dma16(b_base, b_left, lb, b_voff[j]);
       } else {
         unsigned so[NT][B_RPI];
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
   auto advance = [&]() __attribute__((always_inline)) {
     a_base += BK * p.Co;
     a_left = a_left > a_stepb ? a_left - a_stepb : 0;
-    if (p.simple_rows) {
+    if (simple_rows) {
       b_base += BK * p.Ci;
       b_left = b_left > b_stepb ? b_left - b_stepb : 0;
     }
