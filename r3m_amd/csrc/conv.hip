@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // with three accumulator sets: the dY rows of a K step are staged and read from LDS ONCE for the three taps, the scalar cursor
 // walk is shared (the taps differ by one pixel in x) — 2/3 of the DMA instructions and fragment reads per MFMA of the per-tap
 // form. K steps of 16 rows keep the two stages at 64 KB (128-wide tile: 2 blocks per CU as before).
-template <int BMt, int BNt, int BK = 32, int NT = 1, int IL = -1>   // IL: DMA pieces spread between the MFMAs (1), in one burst (0), or p.interleave (-1)
+template <int BMt, int BNt, int BK = 32, int NT = 1, int IL = -1, int SR = -1>   // IL: DMA pieces spread between the MFMAs (1), in one burst (0), or p.interleave (-1); SR: 1x1 "simple rows" known at compile time (1 / 0) or p.simple_rows (-1)
 __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_glds_kernel(const WgradParams p) {
   static_assert(BK == 32 || BK == 16, "K step of 32 or 16 rows");
   static_assert(NT == 1 || NT == 3, "one tap, or the three taps of a kernel row");
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
   constexpr int STAGE = BK * BMt + NT * B_TILE;
   __shared__ __attribute__((aligned(128))) float smem[2 * STAGE];
 
-  const bool simple_rows = NT == 1 && p.simple_rows;   // a kernel-row block (NT = 3) never has 1x1 "simple" rows: resolved at compile time
+  const bool simple_rows = NT == 1 && (SR < 0 ? p.simple_rows != 0 : SR != 0);   // a kernel-row block (NT = 3) never has 1x1 "simple" rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WIDE ? 0 : (wave_s >> 1), wn = WIDE ? wave_s : (wave_s & 1);
@@ -1903,7 +1903,15 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
       p.gx = ceil_div(p.Co, 128) * p.tilesN * p.KH;
       hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 16, 3, 1>), dim3(p.gx * splitK), dim3(256), 0, s, p);
     } else
-    hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    {
+#ifdef R3M_PROBES
+      hipLaunchKernelGGL((wgrad_glds_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#else
+      // shipped builds: the two switches of the per-tap kernel are fixed per launch kind -> two compile-time variants
+      if (p.simple_rows) hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 32, 1, 0, 1>), dim3(tiles * splitK), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 32, 1, 1, 0>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#endif
+    }
   } else {
     p.tilesN = ceil_div(p.Ci, 64);
     const int tiles = ceil_div(p.Co, 64) * p.tilesN * T;
@@ -1917,7 +1925,14 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
       p.gx = ceil_div(p.Co, 64) * p.tilesN * p.KH;
       hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 16, 3, 0>), dim3(p.gx * splitK), dim3(256), 0, s, p);
     } else
-    hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
+    {
+#ifdef R3M_PROBES
+      hipLaunchKernelGGL((wgrad_glds_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#else
+      if (p.simple_rows) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 32, 1, 0, 1>), dim3(tiles * splitK), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 32, 1, 0, 0>), dim3(tiles * splitK), dim3(256), 0, s, p);
+#endif
+    }
   }
   prof_bytes(4.0 * ((double)p.M * p.Co + (double)p.N * p.Hi * p.Wi * p.Ci + (double)splitK * p.Co * T * p.Ci));
   prof_end(s);
