@@ -106,6 +106,8 @@ def parse_args(argv=None):
                     help="with --backend gloo: rank r uses GPU r %% visible GPUs (all ranks on one device of a one-GPU box)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="re-launch under torch.distributed.run also for --gpus 1 (the self-spawn path on a one-GPU box; N > 1 always does)")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="N > 1: do not pin each rank to cores of its GPU's NUMA node (r3m_amd/utils/affinity.py)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short measurements of the other BASELINE configs that the default (headline) run appends under "
                          "'secondary' AFTER the headline's timed region")
@@ -146,6 +148,19 @@ def launch_plan(args, environ, argv, port=None):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else free_port()),
             os.path.abspath(__file__)] + list(argv)
+
+
+def gpu_count_error(gpus, world, local_rank, have, share_gpu):
+    """Message for a rank that cannot get its own GPU (None when fine). Fails BEFORE the process group is created: a rank that
+    dies inside init_process_group leaves the others waiting for the rendezvous timeout."""
+    if share_gpu:
+        return None if have >= 1 else "no GPU visible"
+    if have < 1:
+        return "no GPU visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)"
+    if local_rank >= have:
+        return (f"rank with LOCAL_RANK={local_rank} has no GPU: {have} GPU(s) visible but --gpus {gpus} / WORLD_SIZE={world} asks for one "
+                f"per rank on this node — run with --gpus {have} or make more devices visible")
+    return None
 
 
 def self_spawn(cmd, n, share_gpu=False):
@@ -275,10 +290,14 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
     if sync is not None:
         sync.time_waits(False)
     dt_min = dt_max = dt
+    by_rank = None
     if use_dist:
-        t = torch.tensor([dt, -dt, comm_exposed_ms or 0.0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max, dt_min, comm_exposed_ms = float(t[0].item()), -float(t[1].item()), float(t[2].item())
+        mine = torch.tensor([dt, comm_exposed_ms or 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)                     # every rank's wall time and exposed communication (rank order)
+        by_rank = [(float(t[0].item()), float(t[1].item())) for t in allr]
+        dt_max, dt_min = max(b[0] for b in by_rank), min(b[0] for b in by_rank)
+        comm_exposed_ms = max(b[1] for b in by_rank)
         dt = dt_max
     collectives = ((f"rccl all_reduce(AVG)" if dist.is_initialized() and dist.get_backend() == "nccl" else "gloo all_reduce(SUM)/N")
                    + f", {net.sync.launched / max(1, total_steps):.1f} per step"
@@ -332,6 +351,10 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
             out["ms_per_step_rank_min"] = round(dt_min / steps * 1e3, 3)
             out["ms_per_step_rank_max"] = round(dt_max / steps * 1e3, 3)
             out["comm_exposed_ms"] = round(comm_exposed_ms, 4)     # per step, max over ranks: compute stream idle in work.wait()
+            out["ms_per_step_by_rank"] = [round(b[0] / steps * 1e3, 3) for b in by_rank]
+            out["comm_exposed_ms_by_rank"] = [round(b[1], 4) for b in by_rank]
+            if ctx.get("binding") is not None:
+                out["host_binding"] = ctx["binding"]               # per rank: NUMA node of its GPU, cores, torch threads
         if bf16:
             # with 2-byte activations every ResNet here is under the bf16 ridge -> the bounding roof is HBM.
             # achieved = algorithmic bytes of the dominant kernel class (operands read once + results written once, summed
@@ -397,16 +420,24 @@ def main():
     if cmd is not None:
         raise SystemExit(self_spawn(cmd, args.gpus, args.share_gpu))
 
+    # dmabuf IPC: RCCL across processes needs it on this driver (exported on the GPU boxes; set here too so that a rank started by a
+    # foreign launcher with a scrubbed environment still gets it — the HSA runtime reads it at the first HIP call, below)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # The GPU step needs ONE host thread (plus autograd's); torch's intra-op pool defaults to a thread per core (256 here), and
     # its wake-ups next to the launching thread cost up to +85 ms per 94 ms step of the launch-dense ResNet-34 bf16 workload
     # (measured round 3). cpu_baseline() sets its own thread count afterwards.
     torch.set_num_threads(4)
     if args.share_gpu and args.backend != "gloo":
         raise SystemExit("--share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if args.share_gpu else local_rank
+    have = torch.cuda.device_count()
+    msg = gpu_count_error(args.gpus, world, local_rank, have, args.share_gpu)
+    if msg:
+        raise SystemExit(msg)
+    dev_index = local_rank % max(1, have) if args.share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # Under torch.distributed.run (RANK/MASTER_PORT in the environment) the RCCL process group is ALWAYS created and the
@@ -419,7 +450,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist}
+    ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "binding": None}
+    if use_dist and world > 1 and not args.no_bind and not args.share_gpu:
+        # one rank per GPU on a two-socket host: the launching thread (≈1000 launches per step) stays on cores of its GPU's NUMA
+        # node, ranks get disjoint cores, torch's intra-op pool is capped (round 3: foreign threads next to the launcher cost up
+        # to +85 ms on a 94 ms step)
+        from r3m_amd.utils import affinity
+        info = affinity.bind_rank(local_rank, local_world)
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        ctx["binding"] = infos
 
     w = dict(size=args.size, clips=args.clips_per_gpu, precision=args.precision, langweight=args.langweight, doaug=args.doaug,
              unfused_crop=args.unfused_crop, encoder_only_frames=args.encoder_only_frames)

@@ -219,10 +219,11 @@ int r3m_langrew_forward(const float* alle, const float* feats, const int* perm, 
                         size_t workspace_bytes, int B, int D, int hidden, int lang_dim, r3m_stream_t stream);
 int r3m_langrew_backward(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* workspace,
                          size_t workspace_bytes, int B, int D, int hidden, int lang_dim, int accumulate, r3m_stream_t stream);
-/* The same pass with the MLP's tensors stored in `dtype` (R3M_DT_F32: identical to the calls above; R3M_DT_BF16: what
- * torch.autocast(bfloat16) around the reference's get_reward calls (r3m/trainer.py:72-92) would do — input rows, hidden
+/* The same pass with the MLP's tensors stored in `dtype` (R3M_DT_F32: identical to the calls above; R3M_DT_BF16: mixed precision
+ * in the manner of torch.autocast(bfloat16) around the reference's get_reward calls (r3m/trainer.py:72-92) — input rows, hidden
  * activations and their gradients bf16, every Linear on the bf16 GEMM kernels with fp32 accumulation; master weights, biases,
- * scores, all parameter gradients and dalle stay fp32). Same workspace size; bf16 needs lang_dim % 64 == 0. */
+ * scores, all parameter gradients and dalle stay fp32 — with one difference: a hidden activation is rounded twice (GEMM result
+ * to bf16, then bias + ReLU to bf16) where autocast rounds once). Same workspace size; bf16 needs lang_dim % 64 == 0. */
 int r3m_langrew_forward_dt(const float* alle, const float* feats, const int* perm, const float* params, float* scores, void* workspace,
                            size_t workspace_bytes, int B, int D, int hidden, int lang_dim, int dtype, r3m_stream_t stream);
 int r3m_langrew_backward_dt(const float* dscore, const int* iperm, const float* params, float* grads, float* dalle, void* workspace,

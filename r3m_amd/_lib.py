@@ -139,27 +139,42 @@ def check(rc, what=""):
         raise RuntimeError(f"r3m_hip {what} failed (code {rc}): {last_error()}")
 
 
-_pinned = {}
+_pinned = {}   # (shape, dtype) -> [slots, next]; a slot is [pinned buffer, event of the last copy that read it]
+_PIN_RING = 4
 
 
 def upload_small(t, device, dtype=None):
     """Host tensor -> `device` without stalling the host: a copy from PAGEABLE memory is stream-ordered AND blocks the calling
     thread on ROCm, i.e. the host waits for everything queued before it (the previous step's backward when it sits at the top of a
-    step) and cannot queue ahead. Small per-step tensors (crop boxes, permutations) go through a ring of four pinned staging
-    buffers per (shape, dtype) instead; a buffer is reused four uploads later, by when its copy has long run (Trainer.update
-    waits for the step's metrics, which are queued behind that step's uploads)."""
+    step) and cannot queue ahead. Small per-step tensors (crop boxes, permutations) go through a ring of pinned staging buffers
+    per (shape, dtype) instead. Every slot remembers the event recorded behind the copy that last read it; a slot whose copy has
+    not run yet is NOT overwritten — a caller that is more than four uploads ahead of the GPU (an encoder-only loop that never
+    synchronises, a deep prefetcher) gets a fresh pinned buffer, the ring grows to what that caller needs and stays bounded by
+    how far the host can run ahead."""
     import torch
     if t.is_cuda or torch.device(device).type != "cuda":
         return t.to(device=device, dtype=dtype or t.dtype)
     src = t.to(dtype or t.dtype).contiguous()
     key = (tuple(src.shape), src.dtype)
     ring = _pinned.setdefault(key, [[], 0])
-    if len(ring[0]) < 4:
-        ring[0].append(torch.empty(src.shape, dtype=src.dtype, pin_memory=True))
-    buf = ring[0][ring[1] % len(ring[0])]
-    ring[1] += 1
-    buf.copy_(src)
-    return buf.to(device, non_blocking=True)
+    slots = ring[0]
+    if len(slots) < _PIN_RING:
+        slot = [torch.empty(src.shape, dtype=src.dtype, pin_memory=True), None]
+        slots.append(slot)
+    else:
+        i = ring[1] % len(slots)                        # the oldest slot
+        slot = slots[i]
+        if slot[1] is not None and not slot[1].query():  # its copy has not run yet: leave its host memory alone
+            slot = [torch.empty(src.shape, dtype=src.dtype, pin_memory=True), None]
+            slots.insert(i, slot)                       # the cursor moves on to the still-busy oldest slot
+        ring[1] = i + 1
+    slot[0].copy_(src)
+    with torch.cuda.device(device):
+        out = slot[0].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()                                     # on the stream the copy was queued on (the current one)
+    slot[1] = ev
+    return out
 
 
 def stream_ptr(device=None):

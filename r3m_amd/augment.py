@@ -96,6 +96,12 @@ def crop_resize(frames, boxes, frames_per_box, out_hw=(224, 224)):
     return out
 
 
+class _NotATensor(AttributeError, TypeError):
+    """Raised for tensor attributes a CroppedClips handle does not have. An AttributeError, so that hasattr() / getattr(x, name,
+    default) probing by generic code (collate / transfer helpers, debuggers) keeps working; also a TypeError, which is what direct
+    misuse of the handle as a tensor is."""
+
+
 class CroppedClips:
     """Raw clips + crop boxes standing where the cropped frames [B,T,3,224,224] would stand. The encoder resamples the boxes
     inside its stem pre-pass (r3m_resnet_forward_crop: uint8 -> normalised stem image in one gather pass), so the cropped fp32
@@ -168,7 +174,7 @@ class CroppedClips:
         # only reached for attributes the handle does not have: fail with the contract instead of a bare AttributeError
         if name.startswith("__"):
             raise AttributeError(name)
-        raise TypeError(f"CroppedClips.{name}: the fused rc/rctraj batch is a handle (raw clips + crop boxes), not a tensor; it supports "
+        raise _NotATensor(f"CroppedClips.{name}: the fused rc/rctraj batch is a handle (raw clips + crop boxes), not a tensor; it supports "
                         f"shape / dim / reshape of the leading dims / float / contiguous / record_stream / to / cpu / indexing — call "
                         f".materialize() for the cropped [.., 3, 224, 224] float tensor, or pass fused=False to random_resized_crop")
 

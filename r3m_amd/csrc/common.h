@@ -134,6 +134,8 @@ int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const floa
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
 double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem_bytes);
 int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher will use (stats partial rows)
+bool pw_gemm_eligible(const GatherGemmParams& p);          // conv_pw.hip: persistent kernel for 1x1 / stride-1 launches (fp32)
+int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s);
 int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_pick_split(int M, int Co, int Ci, int T);
 int launch_wgrad_reduce(const float* partial, float* dW, long long n, int splitK, int accumulate, hipStream_t s);

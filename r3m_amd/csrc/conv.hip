@@ -981,6 +981,12 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
         return check_launch("conv3x3_win");
       }
     }
+    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // 1x1 / stride 1: persistent kernel (conv_pw.hip)
+      if (int e = launch_pw_gemm(p, s)) return e;
+      prof_bytes(gather_gemm_alg_bytes(p, 4));
+      prof_end(s);
+      return check_launch("pw_gemm");
+    }
     const int k16_mode = R3M_ENV_INT("R3M_GG_K16", 1);
     const bool short_loop = (p.Ci & 31) == 0 && (k16_mode == 2 || (k16_mode == 1 && p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci));
     if (short_loop) {

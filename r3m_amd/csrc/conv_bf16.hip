@@ -550,6 +550,11 @@ static int gg16_big() {
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);
+  // every loader here addresses the weights (and a frame's worth of activations) through 32-bit buffer offsets
+  R3M_REQUIRE((long long)p.Nc * p.T * p.Ci * 2 < (long long)BUF_OOB, "gather_gemm(bf16): weight tensor of %lld bytes exceeds the 32-bit buffer range",
+              (long long)p.Nc * p.T * p.Ci * 2);
+  R3M_REQUIRE(p.simple_rows || (long long)p.Hi * p.Wi * p.Ci * 2 < (long long)BUF_OOB, "gather_gemm(bf16): one frame of %lld bytes exceeds the 32-bit buffer range",
+              (long long)p.Hi * p.Wi * p.Ci * 2);
   const double flops = 2.0 * (double)p.M * (double)p.Nc * (double)p.ntaps * p.Ci;
   const int nk = p.ntaps * (p.Ci / 64);
   const bool ring = gg16_ring_min() > 0 && nk >= gg16_ring_min();

@@ -1,0 +1,473 @@
+// r3m_amd — persistent pointwise GEMM for gfx950 (MI355X), fp32: the 1x1 / stride-1 convolutions of the bottleneck blocks
+// (forward and dgrad), i.e. out[M x Nc] = A[M x K] * B[Nc x K]^T with contiguous rows on all three sides.
+//
+// Replaces, for these launches, gather_gemm_glds2_kernel / gather_gemm_k16_kernel of conv.hip (same MFMA order, same LDS image:
+// the plain-store and BatchNorm-statistics results are bit-identical to theirs). Reference call site: torchvision Bottleneck
+// conv1 / conv3 / downsample reached from /root/reference/r3m/models/models_r3m.py:99.
+//
+// Why a second kernel. Round 3's launch report: the 1x1 launches are 90 ms of the 149 ms the 128-wide class takes per ResNet-50
+// step and run at 69-128 TFLOP/s while the 1x1 WEIGHT gradients (tiny outputs, no epilogue) reach 135-142. What the forward /
+// dgrad launches pay on top is per-tile: a cold prologue (descriptor set-up, first DMA latency), an epilogue that transposes
+// through LDS with ~4 vector instructions per MFMA for K = 64 (on gfx950 the f32 MFMA shares the SIMD's fp32 lanes with the VALU:
+// vector work is matrix time), and a block boundary whose stores nobody overlaps. Here:
+//   * PERSISTENT blocks (two per CU) walk tiles w, w + W, ...; the two-stage LDS ring is carried ACROSS tiles: the last K step
+//     of a tile carries the DMA of the next tile's first step, so no tile starts cold;
+//   * operands arrive by `buffer_load_dwordx4 ... lds` through wave-uniform descriptors: per-lane offsets are kernel constants,
+//     the K position rides in the instruction's scalar offset, rows past M fall off the descriptor and land zeros — the K loop
+//     holds NO vector ALU instruction;
+//   * the epilogue works straight from the accumulators (32x32 MFMA result layout: a lane owns one COLUMN, its 16 registers are
+//     rows): a `buffer_store_dword` writes two full 128-byte row segments, its row offset is a scalar; BatchNorm partials (forward
+//     statistics, or the backward sums of EPI_BNRED) are in-lane sums over rows; residual-gradient / mask / y operands are read
+//     with the same descriptor arithmetic. No LDS slab, no per-store address arithmetic, no exec masks;
+//   * read-modify-write epilogues (residual-gradient join, EPI_BNRED's y, EPI_ACCUM's old result) PREFETCH their operands into
+//     registers during the last two K steps of the tile, a few loads between every four MFMAs, so that the epilogue itself
+//     waits for nothing (measured with loads inside the epilogue: every sub-tile paid a full HBM latency and these launches ran
+//     5 % SLOWER than in the per-tile kernels whose four blocks per CU hide it). The 1-bit masks of a wave's 64 x 64 tile are ONE
+//     dwordx2 load (lane = row) expanded with ds_bpermute;
+//   * the epilogue of tile i is DEFERRED into the first K step of tile i + 1, after that step's data has landed and the
+//     following step's DMA is issued: the `vmcnt(0)` that publishes the next LDS stage then also covers the stores, one K step
+//     (64 MFMAs per wave) later instead of immediately (gfx9 has one counter for loads and stores).
+#include "common.h"
+#include "conv_dev.h"
+
+namespace r3m {
+
+constexpr int PW_RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit offsets, out-of-range lanes read 0 / store nothing
+
+__device__ __forceinline__ float pw_ld(const void* base, int bytes, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, PW_RSRC_FLAGS), voff, soff, 0));
+#else
+  return 0.f;
+#endif
+}
+__device__ __forceinline__ unsigned pw_ldu(const void* base, int bytes, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, PW_RSRC_FLAGS), voff, soff, 0);
+#else
+  return 0u;
+#endif
+}
+typedef unsigned pw_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pw_u32x2 pw_ld2(const void* base, int bytes, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, PW_RSRC_FLAGS), voff, 0, 0);
+#else
+  return pw_u32x2{0u, 0u};
+#endif
+}
+__device__ __forceinline__ void pw_st(void* base, int bytes, unsigned voff, int soff, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, PW_RSRC_FLAGS), voff,
+                                        soff, 0);
+#endif
+}
+
+// EPI: 0, EPI_STATS, EPI_ACCUM, EPI_MASKED_ADD (1-bit mask only), EPI_BNRED, EPI_BNRED | EPI_MASKED_ADD
+// YBITS (EPI_BNRED): the consumer BatchNorm's ReLU mask comes as bits (block outputs) / is recomputed from y (inner BatchNorms)
+template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
+  static_assert(BM / WM == 64 && BN / WN == 64 && WM * WN == 4, "wave tile is 64 x 64");
+  constexpr int STAGE = (BM + BN) * 32;                 // floats per stage: {A[BM][32], B[BN][32]}, 128-byte rows
+  constexpr int AJ = BM / 32, BJ = BN / 32, NP = AJ + BJ;
+  static_assert(NP == 8 || NP == 10, "piece schedule assumes 8 (128x128) or 10 (256x64) pieces");
+  extern __shared__ __attribute__((aligned(128))) float smem[];
+  float* red = smem + 2 * STAGE;                        // [WM][2][BN]: BatchNorm statistics of the wave rows (EPI_STATS)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s / WN, wn = wave_s % WN;
+  const int W = gridDim.x;
+  const int K = p.Ci, Nc = p.Nc, Kb = K * 4;
+  const int lrow = lane & 31, lh = lane >> 5;
+
+  // ---- DMA: wave w stages rows [w BM/4, +BM/4) of A and [w BN/4, +BN/4) of B, 8 rows (1 KiB) per instruction; the 16-byte
+  // slot a lane fetches is XOR-swizzled by (row >> 1) & 7 (conv.hip, glds2 kernel). Offsets are constants of the kernel.
+  unsigned voffA[AJ], voffB[BJ];
+  {
+    const int srow = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int r = wave_s * (BM / 4) + j * 8 + srow;
+      voffA[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int r = wave_s * (BN / 4) + j * 8 + srow;
+      voffB[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
+    }
+  }
+  auto dma_piece = [&](auto stg_c, auto pc_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
+    constexpr int STG = decltype(stg_c)::value, pc = decltype(pc_c)::value;
+    if constexpr (pc < AJ)
+      buf_dma16(ab, abytes, smem + STG * STAGE + wave_s * (BM / 4) * 32 + pc * 8 * 32, voffA[pc], soff);
+    else
+      buf_dma16(bb, BN * Kb, smem + STG * STAGE + BM * 32 + wave_s * (BN / 4) * 32 + (pc - AJ) * 8 * 32, voffB[pc - AJ], soff);
+  };
+  auto dma_all = [&](auto stg_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
+    static_for<NP>([&](auto pc_c) __attribute__((always_inline)) { dma_piece(stg_c, pc_c, ab, abytes, bb, soff); });
+  };
+  auto a_base = [&](int mt) -> const float* { return p.A + (long long)mt * BM * K; };
+  auto a_bytes = [&](int mt) -> int { return min(BM, p.M - mt * BM) * Kb; };
+  auto b_base = [&](int nt) -> const float* { return p.B + (long long)nt * BN * K; };
+
+  // ---- fragments (as in the glds2 kernel: lane half h reads k = 8g + 4h .. +3 of group g; MFMA j contracts k = {8g + j, 8g + 4 + j})
+  const float* fa[4];
+  const float* fb[4];
+  {
+    const int xr = (lrow >> 1) & 7;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int go = ((2 * g + lh) ^ xr) * 4;
+      fa[g] = smem + (wm * 64 + lrow) * 32 + go;
+      fb[g] = smem + BM * 32 + (wn * 64 + lrow) * 32 + go;
+    }
+  }
+  f32x16 acc[2][2];
+
+  // ---- epilogue operands of the tile being computed, prefetched into registers (read-modify-write epilogues only)
+  // acc[tm][tn][r] is row m0 + wm 64 + tm 32 + 8 (r >> 2) + 4 lh + (r & 3), column n0 + wn 64 + tn 32 + lrow.
+  constexpr bool MADD = (EPI & EPI_MASKED_ADD) != 0, BNR = (EPI & EPI_BNRED) != 0, ACC = (EPI & EPI_ACCUM) != 0;
+  constexpr bool PRE = MADD || BNR || ACC;
+  static_assert(!(MADD && ACC), "one added tensor");
+  const unsigned vo = (unsigned)(((wm * 64 + 4 * lh) * Nc + wn * 64 + lrow) * 4);           // per-lane element offset (bytes) in the tile
+  const int Nw = Nc >> 5;                                                                   // mask words per row
+  const unsigned vow = (unsigned)(((wm * 64 + lane) * Nw + wn * 2) * 4);                    // mask words of row `lane`, this wave's columns
+  float pg[PRE ? 2 : 1][2][16], py[PRE ? 2 : 1][2][16];   // add0 (or the old result) and y of the tile, accumulator layout
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 pgm = {0u, 0u}, pym = {0u, 0u};                   // lane l: the two mask words of tile row wm 64 + l
+  const float* t_gb = nullptr;                            // set per tile (scalars): operand bases at the tile origin + byte counts
+  const float* t_yb = nullptr;
+  const unsigned* t_gbits = nullptr;
+  const unsigned* t_ybits = nullptr;
+  int t_obytes = 0, t_bbytes = 0;
+  auto pre_tile = [&](int tmt, int tnt) __attribute__((always_inline)) {
+    if constexpr (PRE) {
+      const int m0 = tmt * BM, n0 = tnt * BN;
+      const int rows_valid = min(BM, p.M - m0);
+      const long long eo0 = (long long)m0 * Nc + n0;
+      t_obytes = ((rows_valid - 1) * Nc + BN) * 4;        // a lane's offset is inside iff its row is < rows_valid
+      t_bbytes = ((rows_valid - 1) * Nw + BN / 32) * 4;
+      if constexpr (MADD) { t_gb = p.add0 + eo0; t_gbits = p.addbits + (eo0 >> 5); }
+      if constexpr (ACC) t_gb = p.out + eo0;
+      if constexpr (BNR) { t_yb = p.bn_y + eo0; t_ybits = YBITS ? p.bn_bits + (eo0 >> 5) : nullptr; }
+    }
+  };
+  // piece pc of 16: the four rows r = 4 q .. 4 q + 3 of sub-tile (tm, tn), pc = (tm * 2 + tn) * 4 + q; piece 0 also the mask words
+  auto pre_piece = [&](auto pc_c) __attribute__((always_inline)) {
+    if constexpr (PRE) {
+      constexpr int pc = decltype(pc_c)::value;
+      constexpr int tm = pc >> 3, tn = (pc >> 2) & 1, q = pc & 3;
+      // the row stride is made opaque here so that the 64 scalar row offsets of a tile are s_mul'ed where they are used instead
+      // of being hoisted out of the tile loop (they do not fit the SGPR file: 230 spills, each reloaded with a v_readlane)
+      int ncb = Nc * 4;
+      asm volatile("" : "+s"(ncb));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        const int rr = tm * 32 + 8 * q + e;               // 8 (r >> 2) + (r & 3) with r = 4 q + e
+        const int so = rr * ncb + tn * 128;
+        if constexpr (MADD || ACC) pg[tm][tn][r] = pw_ld(t_gb, t_obytes, vo, so);
+        if constexpr (BNR) py[tm][tn][r] = pw_ld(t_yb, t_obytes, vo, so);
+      }
+      if constexpr (pc == 0) {
+        if constexpr (MADD) pgm = pw_ld2(t_gbits, t_bbytes, vow);
+        if constexpr (BNR && YBITS) pym = pw_ld2(t_ybits, t_bbytes, vow);
+      }
+    }
+  };
+
+  // one K step: 64 MFMAs on stage STG_M; FIRST: the accumulators start from zero (C operand = 0, no clears);
+  // DMA: the pieces of another step go out between the MFMAs into stage STG_M ^ 1 (one per 8 MFMAs)
+  auto kstep = [&](auto stgm_c, auto first_c, auto dma_c, auto pf_c, const float* ab, int abytes, const float* bb, int soff, bool do_dma,
+                   bool do_pf) __attribute__((always_inline)) {
+    constexpr int STG_M = decltype(stgm_c)::value, PF = decltype(pf_c)::value;   // PF: 0 none, 1 / 2: first / second half of the tile's epilogue operands
+    constexpr bool FIRST = decltype(first_c)::value, DMA = decltype(dma_c)::value;
+    using SD = std::integral_constant<int, STG_M ^ 1>;
+    // fragments of group g + 1 are requested before the MFMAs of group g (two register sets; one where the prefetched epilogue
+    // operands of EPI_BNRED | EPI_MASKED_ADD leave no room: 64 accumulators + 128 operands)
+    constexpr int FB = (MADD && BNR) ? 1 : 2;
+    f32x4 af[FB][2], bf[FB][2];
+    auto frag_load = [&](auto g_c) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_c)::value;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) af[g % FB][t] = *reinterpret_cast<const f32x4*>(fa[g] + STG_M * STAGE + t * 32 * 32);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bf[g % FB][t] = *reinterpret_cast<const f32x4*>(fb[g] + STG_M * STAGE + t * 32 * 32);
+    };
+    if constexpr (FB == 2) frag_load(std::integral_constant<int, 0>{});
+    static_for<4>([&](auto g_c) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_c)::value;
+      if constexpr (FB == 1) frag_load(g_c);
+      if constexpr (FB == 2 && g < 3) frag_load(std::integral_constant<int, g + 1>{});
+      const f32x4(&a)[2] = af[g % FB];
+      const f32x4(&b)[2] = bf[g % FB];
+      static_for<4>([&](auto j_c) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_c)::value;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            if constexpr (FIRST && g == 0 && j == 0) {
+              const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], z, 0, 0, 0);
+            } else {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+            }
+          }
+        if constexpr (PRE && PF != 0) {
+          // slot s of this step carries operand piece (PF - 1) * 8 + s / 2 (even slots; the DMA pieces ride on the odd ones)
+          constexpr int slot = g * 4 + j;
+          if constexpr ((slot & 1) == 0) {
+            if (do_pf) {
+              __builtin_amdgcn_sched_barrier(0);
+              pre_piece(std::integral_constant<int, (PF - 1) * 8 + (slot >> 1)>{});
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if constexpr (DMA) {
+          // 16 slots of 4 MFMAs; 8 pieces: every second slot; 10 pieces: slots 0..11 except 5 and 11
+          constexpr int slot = g * 4 + j;
+          constexpr bool fire = (NP == 8) ? ((slot & 1) == 1) : (slot < 12 && (slot % 6) != 5);
+          constexpr int piece = (NP == 8) ? (slot >> 1) : (slot - (slot > 5 ? 1 : 0));
+          if constexpr (fire) {
+            if (do_dma) {
+              __builtin_amdgcn_sched_barrier(0);
+              dma_piece(SD{}, std::integral_constant<int, piece>{}, ab, abytes, bb, soff);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      });
+    });
+  };
+
+  // ---- epilogue, part 1 (stores + partial sums), straight from the accumulators of tile (emt, ent); read-modify-write
+  // operands are in pg / py / pgm / pym by now (their loads were waited for with the K step's DMA)
+  const int bp0 = 16 * lh;                                // ds_bpermute byte address of lane 4 lh (the row a lane half adds)
+  auto epilogue1 = [&](int emt, int ent) __attribute__((always_inline)) {
+    const int m0 = emt * BM, n0 = ent * BN;
+    if constexpr ((EPI & EPI_STATS) != 0) {
+      // same summation order as gg_stats (conv_dev.h): rows >= M were staged as zeros and add nothing
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[tm][tn][r];
+            s += v;
+            ss = fmaf(v, v, ss);
+          }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (lane < 32) {
+          const int c = (wn * 2 + tn) * 32 + lane;
+          red[(wm * 2 + 0) * BN + c] = s;
+          red[(wm * 2 + 1) * BN + c] = ss;
+        }
+      }
+    }
+    const int rows_valid = min(BM, p.M - m0);
+    const long long eo0 = (long long)m0 * Nc + n0;                  // element offset of the tile origin
+    const int obytes = ((rows_valid - 1) * Nc + BN) * 4;            // a lane's offset is inside iff its row is < rows_valid
+    float* ob = p.out + eo0;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, mu[2] = {0.f, 0.f}, sc[2] = {0.f, 0.f}, sh[2] = {0.f, 0.f};
+    if constexpr (BNR) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + lrow;
+        mu[tn] = p.bn_mean[col];
+        if constexpr (!YBITS) { sc[tn] = p.bn_scale[col]; sh[tn] = p.bn_shift[col]; }
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        int ncb = Nc * 4;
+        asm volatile("" : "+s"(ncb));                     // see pre_piece: row offsets computed at the point of use
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = tm * 32 + 8 * (r >> 2) + (r & 3);
+          const int so = rr * ncb + tn * 128;
+          float v = acc[tm][tn][r];
+          if constexpr (ACC) v += pg[tm][tn][r];
+          if constexpr (MADD) {
+            const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + rr * 4, (int)pgm[tn]);   // mask word of this element's row
+            v += ((w >> lrow) & 1u) ? pg[tm][tn][r] : 0.f;
+          }
+          pw_st(ob, obytes, vo, so, v);
+          if constexpr (BNR) {
+            const float y = py[tm][tn][r];
+            bool on;
+            if constexpr (YBITS) {
+              const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + rr * 4, (int)pym[tn]);
+              on = ((w >> lrow) & 1u) != 0u;
+            } else {
+              on = fmaf(y, sc[tn], sh[tn]) > 0.f;
+            }
+            const float gg = on ? v : 0.f;
+            s1[tn] += gg;
+            s2[tn] = fmaf(gg, y - mu[tn], s2[tn]);
+          }
+        }
+      }
+    if constexpr (BNR) {
+      // the wave's 64 rows are one partial row of the consumer BatchNorm's backward sums (geometry of bnred_partial_rows)
+      const int g0 = m0 + wm * 64;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        s1[tn] += __shfl_xor(s1[tn], 32);
+        s2[tn] += __shfl_xor(s2[tn], 32);
+        if (lane < 32 && g0 < p.M) {
+          const long long prow = g0 >> 6;
+          const int col = n0 + wn * 64 + tn * 32 + lane;
+          p.stats[(prow * 2 + 0) * Nc + col] = s1[tn];
+          p.stats[(prow * 2 + 1) * Nc + col] = s2[tn];
+        }
+      }
+    }
+  };
+  // part 2 (EPI_STATS, one barrier after part 1): combine the wave rows — stats[mt][2][Nc] as the other kernels write it
+  auto epilogue2 = [&](int emt, int ent) __attribute__((always_inline)) {
+    if constexpr ((EPI & EPI_STATS) != 0) {
+      if (tid < BN) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s += red[(w * 2 + 0) * BN + tid];
+          ss += red[(w * 2 + 1) * BN + tid];
+        }
+        const int col = ent * BN + tid;
+        p.stats[((long long)emt * 2 + 0) * Nc + col] = s;
+        p.stats[((long long)emt * 2 + 1) * Nc + col] = ss;
+      }
+    }
+  };
+
+  // ---- persistent tile walk: workers of one XCD hold neighbouring ids (column tiles of one row panel share that XCD's L2)
+  int id = xcd_remap(blockIdx.x, W);
+  int mt = id / gridN, nt = id - mt * gridN;
+  const int dm = W / gridN, dn = W - dm * gridN;
+  const int npairs = K >> 6;                             // K steps of 32, two per iteration (K is a multiple of 64)
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  bool pending = false;
+  int pmt = 0, pnt = 0;
+  if (id < tiles) dma_all(I0{}, a_base(mt), a_bytes(mt), b_base(nt), 0);
+  while (true) {
+    const bool has = id < tiles;
+    if (has) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0 of this tile has landed (and the previous tile's stores are out,
+      __syncthreads();                                   //  its prefetched epilogue operands are in their registers)
+      dma_all(I1{}, a_base(mt), a_bytes(mt), b_base(nt), 128);
+    }
+    if (pending) epilogue1(pmt, pnt);
+    if (!has) break;
+    pre_tile(mt, nt);
+    kstep(I0{}, T_{}, F_{}, P1{}, nullptr, 0, nullptr, 0, false, npairs == 1);
+    const int nid = id + W;
+    int nmt = mt + dm, nnt = nt + dn;
+    if (nnt >= gridN) { nnt -= gridN; ++nmt; }
+    const bool nhas = nid < tiles;
+    for (int pr = 0; pr < npairs; ++pr) {
+      const bool last = pr + 1 == npairs;
+      if (pr > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (pr == 0 && pending) epilogue2(pmt, pnt);
+      const int tmt = last ? nmt : mt, tnt = last ? nnt : nt;
+      kstep(I1{}, F_{}, T_{}, P2{}, a_base(tmt), a_bytes(tmt), b_base(tnt), last ? 0 : (2 * pr + 2) * 128, last ? nhas : true, last);
+    }
+    pending = true;
+    pmt = mt;
+    pnt = nt;
+    id = nid;
+    mt = nmt;
+    nt = nnt;
+  }
+  if constexpr ((EPI & EPI_STATS) != 0) {
+    if (pending) {
+      __syncthreads();
+      epilogue2(pmt, pnt);
+    }
+  }
+}
+
+// ---- launcher ----------------------------------------------------------------------------------------------------------
+static int pw_cu_count() {
+  static int cus[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+  const bool cached = dev < 32;
+  if (cached) {
+    const int c = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (c > 0) return c;
+  }
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (cached) __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+  return n;
+}
+
+bool pw_gemm_eligible(const GatherGemmParams& p) {
+  if (p.dtype != DT_F32 || p.ntaps != 1 || !p.simple_rows || p.os != 1 || p.T != 1) return false;
+  if (p.dy[0] != 0 || p.dx[0] != 0 || p.wt[0] != 0) return false;
+  if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 127)) return false;
+  switch (p.flags) {
+    case 0: case EPI_STATS: case EPI_ACCUM: case EPI_BNRED: break;
+    case EPI_MASKED_ADD: case EPI_BNRED | EPI_MASKED_ADD:
+      if (!p.addbits) return false;
+      break;
+    default: return false;
+  }
+  return true;
+}
+
+int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  const int gridM = ceil_div(p.M, BM), gridN = p.Nc / BN;
+  const long long tiles_ll = (long long)gridM * gridN;
+  R3M_REQUIRE(tiles_ll < 0x7FFFFFFFLL, "pw_gemm: too many tiles");
+  const int tiles = (int)tiles_ll;
+  const int W = tiles < 2 * pw_cu_count() ? tiles : 2 * pw_cu_count();
+  constexpr int LDS = (2 * (BM + BN) * 32 + 2 * 2 * BN) * 4;
+#define LAUNCH_PW(E, YB)                                                                                                          \
+  do {                                                                                                                           \
+    static DynLdsOptIn oi;                                                                                                       \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, 2, 2, E, YB>), LDS, "pw_gemm")) return e; \
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, 2, 2, E, YB>), dim3(W), dim3(256), LDS, s, p, tiles, gridN);                       \
+  } while (0)
+  const bool yb = p.bn_bits != nullptr;
+  switch (p.flags) {
+    case 0: LAUNCH_PW(0, false); break;
+    case EPI_STATS: LAUNCH_PW(EPI_STATS, false); break;
+    case EPI_ACCUM: LAUNCH_PW(EPI_ACCUM, false); break;
+    case EPI_MASKED_ADD: LAUNCH_PW(EPI_MASKED_ADD, false); break;
+    case EPI_BNRED:
+      if (yb) LAUNCH_PW(EPI_BNRED, true); else LAUNCH_PW(EPI_BNRED, false);
+      break;
+    case EPI_BNRED | EPI_MASKED_ADD:
+      if (yb) LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, true); else LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, false);
+      break;
+    default: set_last_error("pw_gemm: unsupported epilogue flag combination %d", p.flags); return 1;
+  }
+#undef LAUNCH_PW
+  return 0;
+}
+
+}  // namespace r3m

@@ -594,13 +594,24 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   TRY(side_init(P));
   if (stage_begin == 0) {       // the weights are final since the last optimizer step: all dgrad weight images in one launch
     if (!P.d_wt_tab) {
+      // failure-atomic: the plan's pointers are set only after both allocations and both uploads succeeded (a half-initialised
+      // pair would make the next backward skip this block and launch transpose_w_all on a null / uninitialised table)
       const size_t tb = P.wt_tab.size() * sizeof(WtEntry), ib = P.wt_tile0.size() * sizeof(int);
-      if (hipMalloc(reinterpret_cast<void**>(&P.d_wt_tab), tb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&P.d_wt_tile0), ib) != hipSuccess ||
-          hipMemcpy(P.d_wt_tab, P.wt_tab.data(), tb, hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(P.d_wt_tile0, P.wt_tile0.data(), ib, hipMemcpyHostToDevice) != hipSuccess) {
-        set_last_error("resnet_backward: cannot allocate the weight-image table");
+      WtEntry* d_tab = nullptr;
+      int* d_tile0 = nullptr;
+      const bool ok = hipMalloc(reinterpret_cast<void**>(&d_tab), tb) == hipSuccess &&
+                      hipMalloc(reinterpret_cast<void**>(&d_tile0), ib) == hipSuccess &&
+                      hipMemcpy(d_tab, P.wt_tab.data(), tb, hipMemcpyHostToDevice) == hipSuccess &&
+                      hipMemcpy(d_tile0, P.wt_tile0.data(), ib, hipMemcpyHostToDevice) == hipSuccess;
+      if (!ok) {
+        (void)hipGetLastError();
+        if (d_tab) (void)hipFree(d_tab);
+        if (d_tile0) (void)hipFree(d_tile0);
+        set_last_error("resnet_backward: cannot allocate / upload the weight-image table (%zu + %zu bytes)", tb, ib);
         return 1;
       }
+      P.d_wt_tab = d_tab;
+      P.d_wt_tile0 = d_tile0;
     }
     TRY(launch_transpose_w_all(params, arena + P.wt_off, P.d_wt_tab, P.d_wt_tile0, (int)P.wt_tab.size(), P.wt_tile0.back(), P.dtype, s));
   }

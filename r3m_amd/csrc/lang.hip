@@ -229,6 +229,11 @@ static int check_dims(const LangDims& d, int dt = DT_F32) {
 // transposed image; weight gradients: bf16 operands -> fp32 gradients); biases, the final Linear(H -> 1), the scores, all
 // parameter gradients and dalle stay fp32. The bf16 GEMM epilogues in use are the plain stores, so bias + ReLU and the ReLU
 // mask of the backward are two small in-place passes over the [R, H] tensor (3840 x 1024: ~4 us each).
+// Where this is NOT autocast: a hidden activation is rounded TWICE — the GEMM result to bf16, then bf16 + fp32 bias -> ReLU -> bf16
+// — whereas autocast's Linear adds the bias in the fp32 accumulator before its single rounding (one extra half-ulp of bf16 on
+// the pre-activation; the rounding model tests/test_gpu_lang.py checks against has exactly these two roundings). And only the
+// BATCHED training pass runs in bf16: the single-call get_reward / eval path stays fp32, so scores of a precision="bf16" model
+// differ between training and evaluation at bf16 level.
 __global__ __launch_bounds__(256) void bias_relu16_kernel(bf16_t* __restrict__ Z, const float* __restrict__ bias, long long n8, int C8) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;

@@ -52,16 +52,25 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, x, anchor, module, training, crop=None):
         h = module._run_forward(x, training, crop)
         ctx.module = module
-        ctx.generation = module._generation
+        ctx.slot, ctx.generation = module._last_forward
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        ctx.module._run_backward(dh.contiguous(), ctx.generation)
+        ctx.module._run_backward(dh.contiguous(), ctx.generation, ctx.slot)
         return None, None, None, None, None
 
 
 PRECISIONS = {"fp32": 0, "bf16": 1}   # R3M_DT_F32 / R3M_DT_BF16 (include/r3m_hip.h)
+
+
+class _LiveSlot:
+    """Saved state of one forward pass: native plans (per frame count; a plan also carries the staged-backward state), the HBM
+    arena holding that forward's activations, and a generation counter that tells a late backward its activations are gone."""
+    __slots__ = ("plans", "arena", "generation", "F")
+
+    def __init__(self):
+        self.plans, self.arena, self.generation, self.F = {}, None, 0, None
 
 
 class HipResNet(nn.Module):
@@ -69,10 +78,19 @@ class HipResNet(nn.Module):
     stored in bf16 and the convolutions run on the bf16 MFMA with fp32 accumulation; parameters, their gradients, BatchNorm
     statistics and the output embedding stay fp32 (what torch.autocast(bfloat16) around the reference's encoder would do)."""
 
-    def __init__(self, size, precision="fp32"):
+    def __init__(self, size, precision="fp32", max_live_forwards=1):
+        """max_live_forwards: how many forward passes may be waiting for their backward at once. The reference module is a plain
+        autograd graph (/root/reference/r3m/models/models_r3m.py:84-100): h1 = enc(x1); h2 = enc(x2); (h1 + h2).sum().backward()
+        works there. Here a forward's saved activations live in ONE preallocated HBM arena per slot (141 GB for ResNet-50 fp32 at
+        1280 frames), so the default of 1 — all `Trainer.update` needs — makes a second forward invalidate the first one's backward
+        (it raises, it never computes on overwritten activations); k > 1 keeps a ring of k arenas + plans, forwards take them
+        round-robin, and any k consecutive forwards can be backpropagated in any order."""
         super().__init__()
         if precision not in PRECISIONS:
             raise ValueError(f"HipResNet: precision {precision!r} (expected one of {sorted(PRECISIONS)})")
+        if int(max_live_forwards) < 1:
+            raise ValueError("HipResNet: max_live_forwards must be >= 1")
+        self.max_live_forwards = int(max_live_forwards)
         self.precision = precision
         table, n_params, n_buffers, out_dim = _tensor_table(size)
         self.size = size
@@ -105,13 +123,32 @@ class HipResNet(nn.Module):
         self.fc = nn.Identity()   # models_r3m.py:62
         self._flat_p, self._flat_b, self._flat_nbt = flat_p, flat_b, flat_nbt
         self._flat_g = None
-        self._plans = {}          # F -> native handle
-        self._arena = None
-        self._generation = 0
-        self._live_F = None
+        self._ring = [_LiveSlot() for _ in range(self.max_live_forwards)]   # _plans / _arena below are slot 0's
+        self._ring_pos = 0
+        self._last_forward = (0, 0)   # (slot, generation) of the most recent forward
         self._grad_fresh = True
         self._stage_hook = None   # callable(stage, offset, count) after each backward stage (data-parallel wrapper)
         self.reset_parameters()
+
+    @property
+    def _plans(self):             # F -> native handle (slot 0)
+        return self._ring[0].plans
+
+    @_plans.setter
+    def _plans(self, v):
+        self._ring[0].plans = v
+
+    @property
+    def _arena(self):
+        return self._ring[0].arena
+
+    @_arena.setter
+    def _arena(self, v):          # assigning None drops EVERY slot's arena (re-flatten / device move)
+        if v is None:
+            for sl in self._ring:
+                sl.arena = None
+        else:
+            self._ring[0].arena = v
 
     # ---- structure -------------------------------------------------------------------------------------------
     def _resolve(self, dotted):
@@ -231,20 +268,22 @@ class HipResNet(nn.Module):
         return off.value, cnt.value
 
     # ---- execution -------------------------------------------------------------------------------------------
-    def _plan(self, F):
-        h = self._plans.get(F)
+    def _plan(self, F, slot=0):
+        plans = self._ring[slot].plans
+        h = plans.get(F)
         if h is None:
             h = _lib.lib().r3m_resnet_create_dt(self.size, F, PRECISIONS[self.precision])
             if not h:
                 raise RuntimeError(_lib.last_error())
-            self._plans[F] = h
+            plans[F] = h
         return h
 
     def __del__(self):
         try:
             L = _lib.lib()
-            for h in self._plans.values():
-                L.r3m_resnet_destroy(h)
+            for sl in self._ring:
+                for h in sl.plans.values():
+                    L.r3m_resnet_destroy(h)
         except Exception:
             pass
 
@@ -253,7 +292,8 @@ class HipResNet(nn.Module):
         hook belong to THIS object (a copied integer handle would be destroyed twice); the copy re-creates them lazily. The
         reference R3M deep-copies cleanly (plain nn.Module), so must this."""
         st = self.__dict__.copy()
-        st.update(_plans={}, _arena=None, _flat_g=None, _stage_hook=None, _grad_fresh=True, _live_F=None)
+        st.update(_ring=[_LiveSlot() for _ in self._ring], _ring_pos=0, _last_forward=(0, 0), _flat_g=None, _stage_hook=None,
+                  _grad_fresh=True)
         return st
 
     def __setstate__(self, st):
@@ -266,40 +306,47 @@ class HipResNet(nn.Module):
         L = _lib.lib()
         src = crop.raw if crop is not None else x
         F = src.shape[0]
-        h = self._plan(F)
+        si = self._ring_pos                              # forwards take the slots round-robin: the oldest saved forward goes
+        self._ring_pos = (si + 1) % len(self._ring)
+        slot = self._ring[si]
+        h = self._plan(F, si)
         need = L.r3m_resnet_arena_bytes(h)
-        if self._arena is None or self._arena.numel() < need or self._arena.device != src.device:
-            self._arena = None  # release first: the arena is the dominant HBM allocation
-            self._arena = torch.empty(need, dtype=torch.uint8, device=src.device)
+        if slot.arena is None or slot.arena.numel() < need or slot.arena.device != src.device:
+            slot.arena = None   # release first: the arena is the dominant HBM allocation
+            slot.arena = torch.empty(need, dtype=torch.uint8, device=src.device)
+        arena = slot.arena
         out = torch.empty((F, self.outdim), dtype=torch.float32, device=src.device)
         with _lib.on(src):
             if crop is not None:
                 _lib.check(L.r3m_resnet_forward_crop(h, crop.raw.data_ptr(), 1 if crop.raw.dtype == torch.uint8 else 0,
                                                      crop.boxes.data_ptr(), crop.frames_per_box, crop.raw.shape[-2], crop.raw.shape[-1],
-                                                     self._flat_p.data_ptr(), self._flat_b.data_ptr(), self._arena.data_ptr(),
+                                                     self._flat_p.data_ptr(), self._flat_b.data_ptr(), arena.data_ptr(),
                                                      out.data_ptr(), 1 if training else 0, _lib.stream_ptr(src.device)),
                            "resnet_forward_crop")
             else:
                 _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(),
-                                                self._arena.data_ptr(), out.data_ptr(), 1 if training else 0,
+                                                arena.data_ptr(), out.data_ptr(), 1 if training else 0,
                                                 _lib.stream_ptr(x.device)), "resnet_forward")
         if training:
             self._flat_nbt += 1
-        self._generation += 1
-        self._live_F = F
+        slot.generation += 1
+        slot.F = F
+        self._last_forward = (si, slot.generation)
         return out
 
-    def _run_backward(self, dh, generation):
-        if generation != self._generation:
-            raise RuntimeError("r3m_amd: the encoder ran another forward before this backward; its saved activations "
-                               "(one HBM arena per module) were overwritten")
+    def _run_backward(self, dh, generation, si=0):
+        slot = self._ring[si]
+        if generation != slot.generation or slot.arena is None:
+            raise RuntimeError(f"r3m_amd: the encoder ran {len(self._ring)} other forward(s) before this backward; its saved "
+                               f"activations (one HBM arena per live forward) were overwritten. Construct the encoder with "
+                               f"max_live_forwards=k (R3M(..., max_live_forwards=k)) to keep k forwards alive at once")
         L = _lib.lib()
-        h = self._plan(self._live_F)
+        h = self._plan(slot.F, si)
         g = self.flat_grads()
         accumulate = 0 if self._grad_fresh else 1
         with _lib.on(dh):
             for stage in range(4):
-                _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), self._arena.data_ptr(), stage,
+                _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), slot.arena.data_ptr(), stage,
                                                  stage + 1, accumulate, _lib.stream_ptr(dh.device)), "resnet_backward")
                 if self._stage_hook is not None:
                     off, cnt = self.stage_range(stage)

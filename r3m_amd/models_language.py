@@ -205,8 +205,9 @@ class LanguageReward(nn.Module):
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"LanguageReward: precision {precision!r} (fp32 or bf16)")
         # "bf16": the batched training pass stores the MLP's activations bf16 and runs its Linears on the bf16 GEMM kernels (fp32
-        # accumulation, fp32 master weights / gradients) — what autocast(bfloat16) around the reference's get_reward calls does.
-        # The single-call form (forward / R3M.get_reward) stays fp32.
+        # accumulation, fp32 master weights / gradients) — autocast(bfloat16) around the reference's get_reward calls, except that
+        # a hidden activation is rounded twice (GEMM result, then bias + ReLU; csrc/lang.hip). The single-call form (forward /
+        # R3M.get_reward) stays fp32: training-time and evaluation-time scores of a bf16 model differ at bf16 level.
         self.precision = precision
         self.ltype = ltype
         self.sim = simfunc

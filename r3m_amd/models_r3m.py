@@ -34,7 +34,7 @@ class _NormalizeSpec(nn.Module):
 
 class R3M(nn.Module):
     def __init__(self, device, lr, hidden_dim, size=34, l2weight=1.0, l1weight=1.0, langweight=1.0, tcnweight=0.0,
-                 l2dist=True, bs=16, precision="fp32"):
+                 l2dist=True, bs=16, precision="fp32", max_live_forwards=1):
         super().__init__()
         self.device = device
         self.use_tb = False
@@ -53,7 +53,8 @@ class R3M(nn.Module):
         if size not in (18, 34, 50):
             # size == 0 (ViT) is dead code in the reference (NameError: AutoModel never imported, models_r3m.py:53-59)
             raise ValueError(f"R3M: unsupported encoder size {size!r}; the HIP path implements ResNet-18/34/50")
-        self.convnet = HipResNet(size, precision=precision)   # "bf16": mixed-precision encoder (BASELINE configs[2], [4])
+        # "bf16": mixed-precision encoder (BASELINE configs[2], [4]); max_live_forwards: encoder.HipResNet (1 is all Trainer.update needs)
+        self.convnet = HipResNet(size, precision=precision, max_live_forwards=max_live_forwards)
         self.outdim = self.convnet.outdim
         self.normlayer = _NormalizeSpec(IMAGENET_MEAN, IMAGENET_STD)
         self.convnet.train()         # models_r3m.py:63

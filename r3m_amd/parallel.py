@@ -8,9 +8,14 @@ and a shard of the clips; the only exchange is the gradient mean:
   * gradients already sit in ONE flat buffer in layer order, so a "bucket" is a slice — no flatten/unflatten copies;
   * the encoder backward is issued in 4 stages (layer4, layer3, layer2, layer1+stem); after each, the finished slice
     (60 MB, 28 MB, 5 MB, 1 MB for ResNet-50) goes out as an async all-reduce that runs while the next stage computes.
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages keep every link busy, per-tensor ones don't;
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages keep every link busy, per-tensor ones don't.
+    Slices under `min_slice_bytes` (16 MB) are held and merged with the next stage's (they are neighbours in the flat buffer:
+    layer2's slice ends where layer1+stem's begins), so ResNet-50 sends 60 + 28 + 6 MB: the two latency-sized tail
+    messages, which nothing but the last backward stage could hide, become one;
   * BatchNorm statistics stay per-rank (as the reference's DataParallel does per replica chunk); negatives are drawn within
-    the rank's shard.
+    the rank's shard — or, with `global_negatives=True`, across the global batch as the reference does on
+    GPU 0 (trainer.py:41,87,136): one all_gather of the [5B, D] embeddings, the objective evaluated on the gathered batch by
+    every rank with permutations shared from rank 0, and each rank backpropagating its own rows of the gradient.
 
 Both wrappers expose `.module` like DataParallel, which Trainer.update and the snapshot code rely on
 (trainer.py:58-59,72,127,156-158; train_representation.py:126).
@@ -85,6 +90,25 @@ class GradSync:
             dist.broadcast(tensor, src=src, group=self.group)
 
 
+class _GatherRows(torch.autograd.Function):
+    """y = concat over ranks of x (dim 0), differentiable. Every rank evaluates the SAME objective on y (same inputs, shared
+    permutations), so d objective / d x_rank is rows [rank n, (rank + 1) n) of its own d objective / d y — no reduce-scatter. The
+    parameter gradient of the global objective is the SUM over ranks of J_rank^T g_rank while the gradient sync AVERAGES, hence
+    the factor `world`."""
+
+    @staticmethod
+    def forward(ctx, x, group, world, rank):
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x, group=group)
+        ctx.rank, ctx.world, ctx.n = rank, world, x.shape[0]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n] * float(ctx.world), None, None, None
+
+
 class SingleDevice(nn.Module):
     """world_size == 1 stand-in for the reference's DataParallel wrapper: only provides `.module`."""
 
@@ -102,11 +126,17 @@ class SingleDevice(nn.Module):
 class DistributedR3M(nn.Module):
     """One replica per rank. Construct AFTER torch.distributed.init_process_group and after moving `module` to its GPU."""
 
-    def __init__(self, module, process_group=None, force=False):
+    LAST_STAGE = 3   # the engine issues backward in stages 0..3 (layer4, layer3, layer2, layer1 + stem)
+
+    def __init__(self, module, process_group=None, force=False, min_slice_bytes=16 << 20, global_negatives=False):
         super().__init__()
         self.module = module
         self.sync = GradSync(process_group, force=force)
+        # negatives across the GLOBAL batch (off by default: shard-local negatives need no exchange; SURVEY.md §8(e) "optional")
+        self.global_negatives = bool(global_negatives)
         self._head_done = False
+        self.min_slice_bytes = int(min_slice_bytes)
+        self._held = None   # (offset, count) of finished slices not sent yet (smaller than min_slice_bytes so far)
         # identical replicas: rank 0's parameters and BatchNorm buffers win
         for owner in self._owners():
             self.sync.broadcast(owner.flat_params())
@@ -134,22 +164,58 @@ class DistributedR3M(nn.Module):
     def _on_stage(self, stage, offset, count):
         if stage == 0:
             self._reduce_heads()
+        if self._held is not None:
+            ho, hc = self._held
+            if offset + count == ho:          # backward walks the flat buffer downwards: the new slice ends where the held one begins
+                count += hc
+            elif ho + hc == offset:
+                offset, count = ho, hc + count
+            else:                             # not neighbours (never for the engine's stage order): send the held slice by itself
+                self.sync.reduce_slice(self.module.convnet.flat_grads(), ho, hc)
+            self._held = None
+        if stage < self.LAST_STAGE and count * 4 < self.min_slice_bytes:
+            self._held = (offset, count)
+            return
         self.sync.reduce_slice(self.module.convnet.flat_grads(), offset, count)
+
+    def _flush_held(self):
+        if self._held is not None:
+            self.sync.reduce_slice(self.module.convnet.flat_grads(), *self._held)
+            self._held = None
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    # ---- global negatives (Trainer.update calls these when `global_negatives` is set) ----
+    def gather(self, x):
+        """[n, ...] per rank -> [world n, ...] in rank order on every rank; differentiable when x requires grad."""
+        if not self.sync.active:
+            return x
+        rank = dist.get_rank(self.sync.group)
+        if x.requires_grad and torch.is_grad_enabled():
+            return _GatherRows.apply(x, self.sync.group, self.sync.world, rank)
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(self.sync.world)]
+        dist.all_gather(parts, x, group=self.sync.group)
+        return torch.cat(parts, 0)
+
+    def share(self, t):
+        """Rank 0's value of `t` on every rank (in place): the permutations of the global batch must be the same everywhere."""
+        self.sync.broadcast(t, src=0)
+        return t
 
     def finish_gradient_sync(self):
         """Call after backward, before the optimizer step: waits for the slices launched during backward (and reduces the
         head gradients now if no encoder backward ran, e.g. a frozen encoder)."""
         self._reduce_heads()
+        self._flush_held()          # a backward that stopped before the last stage (partial stage range) leaves nothing behind
         self.sync.finish()
         self._head_done = False
 
 
-def make_network_wrapper(model, force=False):
+def make_network_wrapper(model, force=False, global_negatives=False):
     """What `make_network` (train_representation.py:27-31) returns here: DistributedR3M when a process group exists and
     world_size > 1 (or `force`: one-rank group, collectives still issued), else the trivial wrapper."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
-        return DistributedR3M(model, force=force)
+        return DistributedR3M(model, force=force, global_negatives=global_negatives)
     return SingleDevice(model)

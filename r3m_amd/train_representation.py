@@ -34,11 +34,11 @@ def filter_frozen_text_keys(state_dict):
     return {k: v for k, v in state_dict.items() if ".lang_enc." not in k and not k.startswith("lang_enc.")}
 
 
-def make_network(cfg_agent):
+def make_network(cfg_agent, global_negatives=False):
     model = cfgmod.instantiate(cfg_agent)
     dev = torch.device("cuda", torch.cuda.current_device())
     model = model.to(dev)
-    return make_network_wrapper(model)
+    return make_network_wrapper(model, global_negatives=global_negatives)
 
 
 class Workspace:
@@ -63,7 +63,7 @@ class Workspace:
         # batches are copied to HBM (and cropped, for rc/rctraj) one step ahead on a copy stream
         self.train_loader = CudaPrefetcher(mk(train_it), self.device, self._gpu_transform(cfg.doaug, cfg.seed + 31 * self.rank))
         self.val_loader = CudaPrefetcher(mk(val_it), self.device, None)
-        self.model = make_network(cfg.agent)
+        self.model = make_network(cfg.agent, bool(cfg.get("global_negatives", False)))
         self.timer = utils.Timer()
         self._global_step = 0
         if cfg.load_snap:
@@ -133,11 +133,22 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     here = os.path.dirname(os.path.abspath(__file__))
     cfg = cfgmod.load_config(os.path.join(here, "cfgs", "config_rep.yaml"), argv)
+    # dmabuf IPC between the ranks' HIP runtimes (RCCL fails with `hipIpcGetMemHandle: invalid argument` on this driver without
+    # it); read by the HSA runtime at the first HIP call, i.e. set_device below
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    have = torch.cuda.device_count()
+    if local_rank >= have:
+        raise SystemExit(f"LOCAL_RANK={local_rank} but {have} GPU(s) visible: launch one rank per GPU (--nproc-per-node {max(have, 1)})")
     torch.cuda.set_device(local_rank)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # each rank's launcher thread on cores of its GPU's NUMA node, disjoint from the other ranks' (utils/affinity.py)
+        from .utils import affinity
+        info = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        print(f"[rank {dist.get_rank()}] host binding: {info}", flush=True)
     root_dir = Path.cwd() / "r3moutput" / str(cfg.experiment)
     root_dir.mkdir(parents=True, exist_ok=True)
     ws = Workspace(cfg, root_dir)

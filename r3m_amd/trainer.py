@@ -7,6 +7,10 @@
     reference's order (language: (a,b,c) x 3 at :86-92, then TCN: (es0, es2) x 3 at :136-137), uploaded once;
   * the 15 reward-head evaluations are one batched [15B, 2D+768] GEMM chain (models_language.LanguageReward.batched);
     the frozen sentence features are computed once per step instead of 15 times (trainer.py:72-92 -> models_r3m.py:78-81);
+  * with a data-parallel wrapper built with global_negatives=True the rank's [B,5,D] embeddings (and sentence features / mask)
+    are all-gathered first and everything below runs on the global batch, as the reference's DataParallel step does on GPU 0
+    (trainer.py:41: `alles` is the gathered output); permutations are drawn by every rank (same RNG consumption) and rank 0's
+    are used everywhere;
   * all metrics come back in ONE device->host copy instead of ~10 .item() syncs, queued before the backward pass so that the
     host does not wait for the optimizer step (the next step is queued behind it).
 """
@@ -40,6 +44,10 @@ class Trainer:
         b_im_r = b_im.reshape(bs * 5, 3, 224, 224)
         alles = model(b_im_r)
         alle = alles.reshape(bs, 5, -1)
+        gneg = bool(getattr(model, "global_negatives", False))
+        if gneg:
+            alle = model.gather(alle)                # [world * bs, 5, D], differentiable: this rank backpropagates its own rows
+            bs = alle.shape[0]
         t3 = time.time()
 
         # ---- permutations, in the reference's order of torch.randperm draws ----
@@ -51,6 +59,8 @@ class Trainer:
         if core.tcnweight > 0:
             tcn_perm = torch.stack([torch.randperm(bs) for _ in range(2 * core.num_negatives)]).to(torch.int32)
             tcn_perm = _lib.upload_small(tcn_perm, alle.device)      # pinned staging: a pageable copy would stall the host here
+            if gneg:
+                tcn_perm = model.share(tcn_perm)
 
         if core.langweight > 0:
             # b_lang: list[str] as in the reference, or precomputed frozen features [B,768] / (features, mask[B])
@@ -58,13 +68,16 @@ class Trainer:
             if isinstance(b_lang, (tuple, list)) and len(b_lang) == 2 and torch.is_tensor(b_lang[0]):
                 b_lang, lang_mask = b_lang
             feats = core.lang_enc(b_lang).to(alle.device)
-            scores = core.lang_rew.batched_scores(alle, feats, _lib.upload_small(lang_perm, alle.device, torch.int32))
+            lang_perm = _lib.upload_small(lang_perm, alle.device, torch.int32)
             if lang_mask is not None:
                 mask = lang_mask.to(device=alle.device, dtype=torch.float32)
             elif torch.is_tensor(b_lang):
-                mask = torch.ones(bs, dtype=torch.float32, device=alle.device)
+                mask = torch.ones(feats.shape[0], dtype=torch.float32, device=alle.device)
             else:   # videos without language are masked out (trainer.py:107-109)
                 mask = torch.tensor([1.0 * (b != "") for b in b_lang], dtype=torch.float32, device=alle.device)
+            if gneg:
+                feats, mask, lang_perm = model.gather(feats), model.gather(mask), model.share(lang_perm)
+            scores = core.lang_rew.batched_scores(alle, feats, lang_perm)
         t5 = time.time()
 
         full_loss, m = ops.r3m_loss(alle, tcn_perm, core.l2weight, core.l1weight, core.tcnweight, l2dist=core.l2dist,

@@ -94,3 +94,49 @@ def test_gloo_share_gpu_flags_reach_the_ranks():
     cmd = bench.launch_plan(a, {}, argv, port=7)
     assert cmd[-len(argv):] == argv and "--nproc-per-node=2" in cmd
     assert _args().backend == "nccl" and not _args().share_gpu
+
+
+def test_gpu_count_error_is_raised_before_the_process_group():
+    assert bench.gpu_count_error(8, 8, 7, 8, False) is None
+    msg = bench.gpu_count_error(8, 8, 5, 4, False)
+    assert "LOCAL_RANK=5" in msg and "4 GPU(s) visible" in msg and "--gpus 4" in msg
+    assert "no GPU visible" in bench.gpu_count_error(1, 1, 0, 0, False)
+    assert bench.gpu_count_error(2, 2, 1, 1, True) is None          # --share-gpu: two ranks on the one device
+
+
+def test_rank_cpu_plan_follows_the_gpu_numa_node():
+    """N > 1 host placement (r3m_amd/utils/affinity.py): ranks whose GPUs hang off one NUMA node split THAT node's cores into
+    disjoint slices; unknown topology falls back to an even split of the process's CPU set."""
+    from r3m_amd.utils.affinity import parse_cpulist, plan_rank_cpus
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == [] and parse_cpulist("5") == [5]
+    # two sockets x 64 cores (+ SMT siblings 128..255), GPUs 0-3 on node 0, 4-7 on node 1 — the MI355X 8-GPU host layout
+    node_cpus = {0: parse_cpulist("0-63,128-191"), 1: parse_cpulist("64-127,192-255")}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = list(range(256))
+    plans = [plan_rank_cpus(r, nodes, node_cpus, allowed, max_cpus=16) for r in range(8)]
+    for r, p in enumerate(plans):
+        assert len(p) == 16 and set(p) <= set(node_cpus[nodes[r]]), (r, p)
+    for a in range(8):
+        for b in range(a + 1, 8):
+            assert not set(plans[a]) & set(plans[b]), (a, b)          # disjoint: no rank's launcher shares a core with another's
+    assert plans[0][0] == 0 and plans[4][0] == 64
+    # cgroup mask smaller than the node: only allowed cores are used
+    p = plan_rank_cpus(1, [0, 0], {0: list(range(64))}, list(range(8)), max_cpus=16)
+    assert p == [4, 5, 6, 7]
+    # unknown topology (no sysfs node, or numa_node = -1): even split of the allowed set by local rank
+    plans = [plan_rank_cpus(r, [None] * 4, {}, list(range(32)), max_cpus=16) for r in range(4)]
+    assert plans == [list(range(0, 8)), list(range(8, 16)), list(range(16, 24)), list(range(24, 32))]
+    # more ranks than cores: nobody gets an empty mask
+    assert all(plan_rank_cpus(r, [None] * 8, {}, [0, 1], max_cpus=4) for r in range(8))
+
+
+def test_bind_rank_never_raises_and_keeps_a_nonempty_mask():
+    from r3m_amd.utils import affinity
+    before = os.sched_getaffinity(0)
+    try:
+        info = affinity.bind_rank(1, 2, device_indices=[0, 1], set_threads=False)    # no GPU here: topology unknown -> even split
+        assert "error" in info or len(os.sched_getaffinity(0)) >= 1
+        if "error" not in info:
+            assert set(os.sched_getaffinity(0)) <= set(before) and info["cpus"]
+    finally:
+        os.sched_setaffinity(0, before)

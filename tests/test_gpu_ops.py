@@ -28,6 +28,9 @@ CONV_CASES = [
     (5, 7, 512, 2048, 1, 1, 0), (3, 14, 1024, 2048, 1, 2, 0), (5, 7, 2048, 512, 1, 1, 0), (5, 7, 512, 512, 3, 1, 1),
     (2, 56, 64, 128, 3, 2, 1), (2, 56, 64, 128, 1, 2, 0), (2, 28, 128, 256, 3, 2, 1), (3, 14, 256, 512, 3, 2, 1),
     (3, 9, 64, 64, 3, 1, 1), (1, 11, 96, 192, 3, 2, 1), (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1),
+    # persistent 1x1 kernel (conv_pw.hip): more tiles than resident workers (several tiles per worker, deferred epilogues),
+    # partial last row tile, one / two / four K-step pairs per tile
+    (24, 56, 64, 256, 1, 1, 0), (23, 56, 64, 128, 1, 1, 0), (21, 56, 128, 256, 1, 1, 0), (85, 28, 256, 128, 1, 1, 0),
 ]
 
 
@@ -406,7 +409,9 @@ def _pack_bits(mask_nhwc):
 
 BNRED_CASES = [(2, 56, 64, 256, 1, 1, 0), (2, 56, 256, 64, 1, 1, 0), (2, 28, 128, 128, 3, 1, 1), (2, 56, 128, 128, 3, 2, 1),
                (3, 14, 256, 256, 3, 1, 1), (5, 7, 2048, 512, 1, 1, 0), (2, 56, 64, 128, 3, 2, 1), (3, 9, 64, 64, 3, 1, 1),
-               (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1)]
+               (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1),
+               # persistent 1x1 kernel: several tiles per worker, partial last row tile (dgrad: GEMM N = Ci, K = Co)
+               (24, 56, 256, 64, 1, 1, 0), (21, 56, 256, 128, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -76,3 +76,27 @@ def test_next_batch_copy_overlaps_compute(hip):
     assert compute_ms > 20.0
     assert copy_end < compute_ms, "the H2D copy waited for the compute stream instead of overlapping it"
     assert torch.equal(x.cpu(), frames[0].float())
+
+
+def test_small_uploads_survive_a_host_that_runs_far_ahead(hip):
+    """_lib.upload_small stages per-step tensors (crop boxes, permutations) in a ring of pinned buffers. A caller that never
+    synchronises (an encoder-only loop, a deep prefetcher) can be more than a ring ahead of the GPU: a slot whose copy has not
+    run yet must not be overwritten (silently corrupted boxes). 64 uploads are queued behind ~0.3 s of GPU work."""
+    from r3m_amd import _lib
+    _lib._pinned.clear()
+    a = torch.randn((8192, 8192), device=DEV)
+    torch.cuda.synchronize()
+    for _ in range(24):
+        a = (a @ a) * 1e-2                                           # keeps the stream busy while the host queues the uploads
+    outs = [_lib.upload_small(torch.full((4, 6), i, dtype=torch.int64), DEV, torch.int32) for i in range(64)]
+    ring = _lib._pinned[((4, 6), torch.int32)][0]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert o.dtype == torch.int32 and o.device == DEV
+        assert torch.equal(o.cpu(), torch.full((4, 6), i, dtype=torch.int32)), f"upload {i} was overwritten before its copy ran"
+    assert len(ring) >= 4                                            # the ring grew instead of recycling busy slots ...
+    n = len(ring)
+    for i in range(16):                                              # ... and with the GPU idle it stops growing
+        _lib.upload_small(torch.full((4, 6), i, dtype=torch.int64), DEV, torch.int32)
+        torch.cuda.synchronize()
+    assert len(ring) == n

@@ -55,6 +55,14 @@ def _worker(rank, world, port, q):
         net2 = make_network_wrapper(m2)
         head = m2.lang_rew
         hg = head.flat_grads()
+        # slices under min_slice_bytes wait for the next stage and go out merged (ResNet-18: 33.6 MB, then 8.4 + 2.1 + 0.6 MB as one)
+        sizes = [m2.convnet.stage_range(st)[1] * 4 for st in range(4)]
+        n_enc, held = 0, 0
+        for st in range(4):
+            held += sizes[st]
+            if st == 3 or held >= net2.min_slice_bytes:
+                n_enc, held = n_enc + 1, 0
+        assert n_enc == 2 and sizes[0] >= net2.min_slice_bytes > sizes[1] + sizes[2] + sizes[3]
         for step in range(2):
             hg.fill_(float(rank + 1 + step))
             head._has_grads = True
@@ -66,9 +74,11 @@ def _worker(rank, world, port, q):
                 m2.convnet._stage_hook(stage, off, cnt)
                 if stage == 0:
                     assert net2.sync.launched == before + 2          # head buffer + the layer4 slice
-            assert net2.sync.launched == before + 5
+                if stage in (1, 2):
+                    assert net2.sync.launched == before + 2 and net2._held is not None   # small slices are held back
+            assert net2.sync.launched == before + 1 + n_enc
             net2.finish_gradient_sync()
-            assert net2.sync.launched == before + 5                  # nothing left for finish() to issue
+            assert net2.sync.launched == before + 1 + n_enc          # nothing left for finish() to issue
             assert torch.allclose(hg, torch.full_like(hg, (sum(range(1, world + 1)) / world) + step))
             assert torch.allclose(g2, torch.full_like(g2, 10 * sum(range(1, world + 1)) / world))
         # a step without encoder backward (no stage hook fired): finish() still reduces the head
@@ -77,6 +87,29 @@ def _worker(rank, world, port, q):
         before = net2.sync.launched
         net2.finish_gradient_sync()
         assert net2.sync.launched == before + 1 and torch.allclose(hg, torch.full_like(hg, (world - 1) / 2.0))
+        # a backward that ends early (stages 0..1 only) leaves a held slice: finish() sends it; min_slice_bytes=0 restores one
+        # collective per stage
+        g2 = m2.convnet.flat_grads()
+        g2.fill_(float(rank + 1))
+        hg.fill_(0.0)
+        head._has_grads = True
+        before = net2.sync.launched
+        for stage in range(2):
+            m2.convnet._stage_hook(stage, *m2.convnet.stage_range(stage))
+        assert net2._held is not None
+        net2.finish_gradient_sync()
+        assert net2._held is None and net2.sync.launched == before + 3
+        o1, c1 = m2.convnet.stage_range(1)
+        assert torch.allclose(g2[o1:o1 + c1], torch.full((c1,), sum(range(1, world + 1)) / world))
+        o2, c2 = m2.convnet.stage_range(2)
+        assert torch.allclose(g2[o2:o2 + c2], torch.full((c2,), float(rank + 1)))       # stage 2 never ran: untouched
+        net2.min_slice_bytes = 0
+        head._has_grads = False
+        before = net2.sync.launched
+        for stage in range(4):
+            m2.convnet._stage_hook(stage, *m2.convnet.stage_range(stage))
+        net2.finish_gradient_sync()
+        assert net2.sync.launched == before + 4
         # one-rank semantics of `force` are exercised on the GPU (tests/test_gpu_ddp.py); here: world 2 is active without it
         assert net2.sync.active
         # plain GradSync on an arbitrary buffer + no-op at count 0
@@ -100,6 +133,94 @@ def test_gradient_sync_world2_gloo():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in res:
+        assert status == "ok", f"rank {rank}: {status}"
+
+
+def _gneg_worker(rank, world, port, q):
+    """global_negatives (/root/reference/r3m/trainer.py:41,87,136 — DataParallel gathers the embeddings and GPU 0
+    draws negatives from the WHOLE batch): 2 ranks x B/2 clips, embeddings gathered, the oracle's objective evaluated on the gathered
+    batch by every rank with rank 0's permutations, each rank backpropagating its own rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import r3m_ref
+        from r3m_amd import R3M
+        from r3m_amd.parallel import DistributedR3M
+        B, D, Fin = 6, 32, 20                             # global batch of 6 clips; "encoder" = one linear map R^20 -> R^32
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn((B, 5, Fin), generator=g)
+        theta0 = torch.randn((Fin, D), generator=g) * 0.3
+        feats = torch.randn((B, 768), generator=g) * 0.3
+        mask = torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0, 1.0])
+        tcn_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(6)])
+        lang_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(9)])
+        ref = r3m_ref.R3MRef(size=18, hidden_dim=16, l2weight=1e-2, l1weight=1e-2, langweight=1.0, tcnweight=1.0)
+        ref.outdim = D
+        torch.manual_seed(9)
+        ref.lang_rew = r3m_ref.LanguageRewardRef(D, 16, 768)
+
+        # single process, whole batch
+        th = theta0.clone().requires_grad_(True)
+        loss1, m1, _ = r3m_ref.r3m_loss_ref(ref, X @ th, tcn_perm, feats, mask, lang_perm)
+        ref.zero_grad()
+        loss1.backward()
+        g_theta1 = th.grad.clone()
+        g_head1 = torch.cat([p.grad.reshape(-1) for p in ref.lang_rew.parameters()])
+
+        # two ranks, B/2 clips each, negatives across the global batch
+        m = R3M("cpu", 1e-4, 16, size=18, langweight=0.0, tcnweight=1.0)
+        net = DistributedR3M(m, global_negatives=True)
+        assert net.global_negatives and not DistributedR3M(m).global_negatives      # off by default
+        n = B // world
+        th = theta0.clone().requires_grad_(True)
+        local = X[rank * n:(rank + 1) * n] @ th
+        alle = net.gather(local)
+        assert alle.shape == (B, 5, D) and alle.requires_grad
+        assert torch.equal(alle.detach(), X @ theta0)                               # rank order, bit-identical rows
+        f_all, k_all = net.gather(feats[rank * n:(rank + 1) * n]), net.gather(mask[rank * n:(rank + 1) * n])
+        assert torch.equal(f_all, feats) and torch.equal(k_all, mask) and not f_all.requires_grad
+        # every rank draws its own permutations (different RNG streams); rank 0's win
+        torch.manual_seed(1000 + rank)
+        mine = torch.stack([torch.randperm(B) for _ in range(6)])
+        shared = net.share(mine.clone())
+        ref0 = mine.clone()
+        dist.broadcast(ref0, src=0)
+        assert torch.equal(shared, ref0)
+        loss2, m2, _ = r3m_ref.r3m_loss_ref(ref, alle, tcn_perm, f_all, k_all, lang_perm)
+        assert m2 == m1, (m1, m2)                                                   # the loss scalars of the 1-rank step, bit for bit
+        ref.zero_grad()
+        loss2.backward()
+        # encoder: the gradient sync AVERAGES the ranks' parameter gradients -> the single-process gradient of the global objective
+        gth = th.grad.clone()
+        dist.all_reduce(gth)
+        gth /= world
+        torch.testing.assert_close(gth, g_theta1, rtol=1e-5, atol=1e-7)
+        # head: evaluated on the global batch by every rank -> every rank already holds the full gradient (the mean changes nothing)
+        g_head2 = torch.cat([p.grad.reshape(-1) for p in ref.lang_rew.parameters()])
+        torch.testing.assert_close(g_head2, g_head1, rtol=1e-6, atol=1e-8)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_negatives_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gneg_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of single conv launches through the C ABI (GPU only).
-usage: conv_bench.py [fwd|wgrad|fwd16|wgrad16] N,H,Ci,Co,k,s,p ...      (the *16 modes run the bf16 kernels)"""
+usage: conv_bench.py [fwd|wgrad|dgradbn|dgradbnres|fwd16|wgrad16|...] N,H,Ci,Co,k,s,p ...   (the *16 modes run the bf16 kernels)
+dgradbn: dgrad with the EPI_BNRED epilogue (mask recomputed from y); dgradbnres: + mask bits + masked residual-gradient join"""
 import os
 import sys
 import torch
@@ -27,6 +28,24 @@ for spec in sys.argv[2:]:
         rows = L.r3m_conv2d_stats_rows(N, H, H, Co, k, s, p)
         stats = torch.empty((rows, 2, Co), device="cuda")
         fn = lambda: L.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, dt, st)
+    elif mode in ("dgradbn", "dgradbnres"):
+        dy = torch.randn_like(y)
+        dx = torch.empty_like(x)
+        by = torch.randn_like(x)
+        res = torch.randn_like(x) if mode == "dgradbnres" else None
+        nbits = x.numel() // 32
+        rbits = torch.randint(-2 ** 31, 2 ** 31 - 1, (nbits,), device="cuda", dtype=torch.int32) if mode == "dgradbnres" else None
+        ybits = torch.randint(-2 ** 31, 2 ** 31 - 1, (nbits,), device="cuda", dtype=torch.int32) if mode == "dgradbnres" else None
+        sc, sh, mu = torch.rand(Ci, device="cuda") + 0.5, torch.rand(Ci, device="cuda") - 0.5, torch.rand(Ci, device="cuda")
+        rows = L.r3m_conv2d_dgrad_bnred_rows(N, H, H, s)
+        part = torch.empty((rows, 2, Ci), device="cuda")
+        wsb = L.r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+        wf = w.float()
+        P = lambda t: None if t is None else t.data_ptr()
+        fn = lambda: L.r3m_conv2d_dgrad_bnred_dt(dy.data_ptr(), wf.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p,
+                                                 P(res), P(rbits), by.data_ptr(), P(ybits), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                                                 part.data_ptr(), dt, st)
     else:
         dy = torch.randn_like(y)
         dw = torch.empty(w.shape, device="cuda")
