@@ -25,8 +25,9 @@
 //     5 % SLOWER than in the per-tile kernels whose four blocks per CU hide it). The 1-bit masks of a wave's 64 x 64 tile are ONE
 //     dwordx2 load (lane = row) expanded with ds_bpermute;
 //   * the epilogue of tile i is DEFERRED into the first K step of tile i + 1, after that step's data has landed and the
-//     following step's DMA is issued: the `vmcnt(0)` that publishes the next LDS stage then also covers the stores, one K step
-//     (64 MFMAs per wave) later instead of immediately (gfx9 has one counter for loads and stores).
+//     following step's DMA is issued. gfx9 has ONE in-order counter for loads and stores: the wait that publishes the next LDS
+//     stage is `vmcnt(63)` there — the DMA is older than the 64 stores — so the stores are first waited for one further K step
+//     later, with the DMA of the step after that.
 #include "common.h"
 #include "conv_dev.h"
 
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   }
   auto dma_piece = [&](auto stg_c, auto pc_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
     constexpr int STG = decltype(stg_c)::value, pc = decltype(pc_c)::value;
+    if (R3M_PROBE(p) & 8) return;                         // timing probe: no DMA (stale LDS)
     if constexpr (pc < AJ)
       buf_dma16(ab, abytes, smem + STG * STAGE + wave_s * (BM / 4) * 32 + pc * 8 * 32, voffA[pc], soff);
     else
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   const int bp0 = 16 * lh;                                // ds_bpermute byte address of lane 4 lh (the row a lane half adds)
   auto epilogue1 = [&](int emt, int ent) __attribute__((always_inline)) {
     const int m0 = emt * BM, n0 = ent * BN;
-    if constexpr ((EPI & EPI_STATS) != 0) {
+    if (R3M_PROBE(p) & 4) return;                         // timing probes (probe builds only; wrong results)
+    if ((EPI & EPI_STATS) != 0 && !(R3M_PROBE(p) & 2)) {
       // same summation order as gg_stats (conv_dev.h): rows >= M were staged as zeros and add nothing
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
             const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + rr * 4, (int)pgm[tn]);   // mask word of this element's row
             v += ((w >> lrow) & 1u) ? pg[tm][tn][r] : 0.f;
           }
-          pw_st(ob, obytes, vo, so, v);
+          if (!(R3M_PROBE(p) & 1)) pw_st(ob, obytes, vo, so, v);
           if constexpr (BNR) {
             const float y = py[tm][tn][r];
             bool on;
@@ -387,8 +390,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
         __syncthreads();
         kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // The counter is in order over loads AND stores on gfx9 (no separate store counter; the compiler's own waits rely on it):
+      // right after a deferred epilogue the 64 stores of this wave are YOUNGER than the DMA this step needs, so "all but the 63
+      // most recent" = that DMA (+ one store) — the stores keep flying under this step's MFMAs instead of being waited for here
+      // (timing probe: with the stores removed the K = 64 launch runs 1.20 instead of 1.61 ms; their L2 acknowledgement under a
+      // 2.6 TB/s write load takes longer than the 64 MFMAs that used to separate issue and wait).
+      // (__syncthreads() carries a workgroup-scope release fence = vmcnt(0); the hand-off here is LDS only — DMA landed per wave,
+      // `red` written with lgkmcnt(0) — so a bare s_barrier is enough.)
+      if (pr == 0 && pending && !(R3M_PROBE(p) & (1 | 4 | 16))) {
+        asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       if (pr == 0 && pending) epilogue2(pmt, pnt);
       const int tmt = last ? nmt : mt, tnt = last ? nnt : nt;
       kstep(I1{}, F_{}, T_{}, P2{}, a_base(tmt), a_bytes(tmt), b_base(tnt), last ? 0 : (2 * pr + 2) * 128, last ? nhas : true, last);

@@ -6,7 +6,12 @@ Inputs and weights come from oracle/detgen.py (hash generator) so they are NOT s
                                    L = sum(h * cw) (full conv1/bn1 grads + L2 norm of every parameter gradient)
   G3     loss_{l2,cos}.npz       : reference Trainer.update on given embeddings (fake encoder), TCN + LP + language
                                    InfoNCE with the reference LanguageReward: metrics, d full_loss/d alle, scores, head grads
-  G5     step_r18.npz            : two full reference Trainer.update steps (R3M + Adam), B=2 clips
+  G5     step_r{18,34,50}.npz    : two full reference Trainer.update steps (R3M + Adam), B=2 clips
+  G8     encoder_r{18,34,50}_nokink.npz : the G1/G2 gradient case on the KINK-FREE state (detgen.resnet_state_dict_no_kink, tag
+                                   "nk2", shift 4.0; tools/experiments/find_nokink.py): no float64 pre-activation of the last
+                                   block lies within 1.3e-3 of zero, so every fp32 forward makes the float64 ReLU decisions
+                                   there and the gradient gate (3x the reference's own fp32 error) applies with NO flip
+                                   accounting. Holds the reference's fp32 results AND the float64 oracle's.
 """
 import os
 import sys
@@ -88,6 +93,67 @@ def encoder_fp64_golden(size, F=8):
     np.savez_compressed(os.path.join(OUT, f"encoder_r{size}_fp64.npz"), **out)
     e = np.linalg.norm(g32["grad_conv1.weight"].astype(np.float64) - P["conv1.weight"].grad.numpy()) / np.linalg.norm(P["conv1.weight"].grad.numpy())
     print("fp64", size, "reference-fp32 conv1.weight grad l2-rel vs fp64:", e)
+
+
+NK_TAG, NK_SHIFT, NK_FRAMES = "nk2", 4.0, "frames8nk"
+GRAD_KEYS = lambda lb: ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight",  # noqa: E731
+                        "layer2.0.downsample.0.weight")
+
+
+def encoder_nokink_golden(size, F=8):
+    """G8: reference fp32 (its own R3M.forward + autograd) and float64 oracle on the kink-free state, in one file."""
+    from oracle import r3m_ref
+    r3m, _, _ = by_path.load_reference()
+    lb = last_bn_name(size)
+
+    def state(convnet):
+        shapes = [(k, tuple(v.shape)) for k, v in convnet.state_dict().items()]
+        sd = detgen.resnet_state_dict_no_kink(shapes, size, tag=NK_TAG, shift=NK_SHIFT)
+        convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+
+    x = torch.from_numpy(detgen.frames(NK_FRAMES, (F, 3, 224, 224)))
+    out = {}
+    # the reference, fp32
+    m = r3m.R3M("cpu", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0)
+    state(m.convnet)
+    m.train()
+    h = m(x)
+    out["h_train"] = h.detach().numpy()
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5))
+    (h * cw).sum().backward()
+    P = dict(m.convnet.named_parameters())
+    names = list(P.keys())
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array([float(P[k].grad.double().norm()) for k in names], dtype=np.float64)
+    for k in GRAD_KEYS(lb):
+        out["grad_" + k] = P[k].grad.numpy().copy()
+    # the oracle, float64 (+ the last block's pre-activations: how far from a kink the case is)
+    o = r3m_ref.R3MRef(size=size, langweight=0.0, tcnweight=1.0)
+    state(o.convnet)
+    o = o.double()
+    o.train()
+    net = o.convnet
+    blk = net.layer4[-1]
+    last = blk.bn3 if size == 50 else blk.bn2
+    keep = {}
+    hooks = [last.register_forward_hook(lambda mod, i, o_: keep.__setitem__("bn_out", o_.detach())),
+             blk.register_forward_pre_hook(lambda mod, i: keep.__setitem__("idn", i[0].detach()))]
+    h64 = net(o.normlayer(x.double() / 255.0))
+    for hk in hooks:
+        hk.remove()
+    z = (keep["bn_out"] + keep["idn"]).flatten()
+    out["min_abs_z"] = np.array(float(z.abs().min()))
+    out["frac_z_negative"] = np.array(float((z < 0).double().mean()))
+    assert float(z.abs().min()) > 1e-3, "not kink-free: rerun tools/experiments/find_nokink.py"
+    (h64 * cw.double()).sum().backward()
+    P64 = dict(net.named_parameters())
+    out["h_train_fp64"] = h64.detach().numpy()
+    out["grad_norms_fp64"] = np.array([float(P64[k].grad.norm()) for k in names], dtype=np.float64)
+    for k in GRAD_KEYS(lb):
+        out["grad64_" + k] = P64[k].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"encoder_r{size}_nokink.npz"), **out)
+    e = np.linalg.norm(out["grad_conv1.weight"].astype(np.float64) - P64["conv1.weight"].grad.numpy()) / np.linalg.norm(P64["conv1.weight"].grad.numpy())
+    print("nokink", size, "min|z|", float(out["min_abs_z"]), "frac z<0", float(out["frac_z_negative"]), "reference-fp32 conv1 grad vs fp64:", e)
 
 
 def encoder_kink_golden(size, F=8, tau=2e-4):
@@ -242,8 +308,10 @@ def step_golden(size=18, B=2, nsteps=2):
         out["metric_names"] = np.array(list(metrics.keys()))
         out[f"perms_{s}"] = perms[s].numpy()
     sd = m.convnet.state_dict()
-    for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "layer4.1.bn2.weight",
-              "layer4.1.conv2.weight", "layer1.0.conv1.weight"):
+    lb = last_bn_name(size)
+    last_conv = lb.replace("bn", "conv")
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", lb + ".weight",
+              last_conv + ".weight", "layer1.0.conv1.weight"):
         out["post_" + k] = sd[k].numpy().copy() if sd[k].numel() < 50000 else sd[k].numpy().reshape(-1)[:50000].copy()
     out["nbt"] = sd["bn1.num_batches_tracked"].numpy().copy()
     np.savez_compressed(os.path.join(OUT, f"step_r{size}.npz"), **out)
@@ -322,9 +390,11 @@ if __name__ == "__main__":
         encoder_golden(size)
         encoder_fp64_golden(size)
         encoder_kink_golden(size)
+        encoder_nokink_golden(size)
     loss_golden(True)
     loss_golden(False)
-    step_golden()
+    for size in (18, 34, 50):
+        step_golden(size)
     language_reward_golden(512)
     language_reward_golden(2048)
     adam_golden()

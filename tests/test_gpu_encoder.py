@@ -203,14 +203,16 @@ def test_tcn_lp_loss_matches_reference_golden(hip, golden_dir, l2dist):
     assert e_max < 1e-4
 
 
-def test_full_step_matches_reference_golden(hip, golden_dir):
-    """G5: two Trainer.update steps (encoder + loss + backward + Adam) on ResNet-18, B = 2 clips."""
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_full_step_matches_reference_golden(hip, golden_dir, size):
+    """G5: two Trainer.update steps (encoder + loss + backward + Adam), B = 2 clips, ResNet-18 / 34 / 50 (the reference's own
+    Trainer.update + torch.optim.Adam on CPU made the vectors: tests/golden/make_golden.py::step_golden)."""
     from oracle import detgen
     from r3m_amd import R3M
     from r3m_amd.parallel import SingleDevice
     from r3m_amd.trainer import Trainer
-    g = np.load(os.path.join(golden_dir, "step_r18.npz"))
-    m = R3M("cuda", 1e-4, 1024, size=18, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    g = np.load(os.path.join(golden_dir, f"step_r{size}.npz"))
+    m = R3M("cuda", 1e-4, 1024, size=size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
     _load_state(m.convnet)
     model = SingleDevice(m).to(DEV)
     frames = torch.from_numpy(detgen.frames("stepframes", (2, 5, 3, 224, 224))).to(DEV)
@@ -229,7 +231,7 @@ def test_full_step_matches_reference_golden(hip, golden_dir):
             assert abs(metrics[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (s, k, metrics[k], ref[k])
     sd = m.convnet.state_dict()
     lr = 1e-4
-    for k in ("bn1.weight", "bn1.bias", "layer4.1.bn2.weight", "conv1.weight"):
+    for k in ("bn1.weight", "bn1.bias", _last_bn(size) + ".weight", "conv1.weight"):
         got = sd[k].cpu().numpy().reshape(-1)[:50000]
         ref = g["post_" + k].reshape(-1)
         d = np.abs(got - ref)
@@ -378,3 +380,43 @@ def test_second_forward_before_backward(hip):
     with pytest.raises(RuntimeError, match="max_live_forwards"):
         h1.sum().backward()
     (h2.sum() + h3.sum()).backward()
+
+
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_encoder_gradients_kink_free_case(hip, golden_dir, size):
+    """G8: the gradient gate with NO escape hatch. On the kink-free state (detgen.resnet_state_dict_no_kink:
+    no float64 pre-activation of the last block within 1.3e-3 of zero, tests/golden/encoder_r*_nokink.npz) every fp32 forward
+    makes the float64 ReLU decisions of the last block, so the HIP gradients are gated against float64 at <= 3x the error of the
+    reference's own PyTorch-CPU fp32 gradients of the same tensor (floor 1e-4) — unconditionally: no flip table, no re-evaluation
+    of the oracle with imposed decisions (that machinery stays a diagnostic on the G1/G2 case above)."""
+    from oracle import detgen
+    from r3m_amd import R3M
+    g = np.load(os.path.join(golden_dir, f"encoder_r{size}_nokink.npz"))
+    assert float(g["min_abs_z"]) > 1e-3
+    m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0).to(DEV)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    sd = detgen.resnet_state_dict_no_kink(shapes, size, tag="nk2", shift=4.0)
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.train()
+    x = torch.from_numpy(detgen.frames("frames8nk", (8, 3, 224, 224))).to(DEV)
+    h = m(x)
+    e = rel_err(h.detach().cpu().numpy(), g["h_train"])[0]
+    e64 = rel_err(h.detach().cpu().numpy(), g["h_train_fp64"])[0]
+    report(f"r{size} kink-free: train-mode embedding max-rel vs reference fp32 {e:.2e}, vs float64 {e64:.2e}")
+    assert e < 1e-4
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).to(DEV)
+    (h * cw).sum().backward()
+    P = dict(m.convnet.named_parameters())
+    worst_hip = worst_cpu = 0.0
+    for name, n32, n64 in zip(g["grad_names"], g["grad_norms"], g["grad_norms_fp64"]):
+        got = float(P[str(name)].grad.double().norm())
+        worst_hip = max(worst_hip, abs(got - n64) / max(n64, 1e-12))
+        worst_cpu = max(worst_cpu, abs(n32 - n64) / max(n64, 1e-12))
+    report(f"r{size} kink-free: grad-norm worst rel vs fp64: hip {worst_hip:.3e}  reference-cpu-fp32 {worst_cpu:.3e}")
+    assert worst_hip <= max(3.0 * worst_cpu, 1e-4)
+    lb = _last_bn(size)
+    for k in ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight"):
+        hip_err = rel_err(P[k].grad.cpu().numpy(), g["grad64_" + k])[1]
+        cpu_err = rel_err(g["grad_" + k], g["grad64_" + k])[1]
+        report(f"r{size} kink-free grad {k}: l2-rel vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}  ratio {hip_err / max(cpu_err, 1e-12):.2f}")
+        assert hip_err <= max(3.0 * cpu_err, 1e-4), (k, hip_err, cpu_err)

@@ -277,3 +277,53 @@ def test_midsize_train_mode_resnet50_vs_oracle(hip):
         worst_cpu = max(worst_cpu, abs(n32[k] - n64[k]) / max(n64[k], 1e-12))
     print(f"r50 F={F} train: grad-norm worst rel vs float64: hip {worst_hip:.3e} ({worst_k})  oracle-fp32 {worst_cpu:.3e}")
     assert worst_hip <= max(3.0 * worst_cpu, 1e-4), (worst_hip, worst_k, worst_cpu)
+
+
+def test_bench_size_train_forward_vs_oracle(hip):
+    """the oracle AT the bench size. Train-mode forward of the headline workload's 1280 frames through ResNet-50
+    fp32 (batch statistics over 1280 x H x W elements per channel; the statistics partials, their fp64 combine and every forward
+    kernel at the tile counts of the benchmark) against oracle/r3m_ref.py evaluated on this box's CPU (no_grad, ~1 min): embeddings
+    and the running statistics the pass leaves in bn1 / the last BatchNorm, gate 1e-4 max-rel (BASELINE.json north_star; reference
+    arithmetic: /root/reference/r3m/models/models_r3m.py:97-99). Skipped on hosts without the memory for the CPU side."""
+    import os
+    from oracle import detgen, r3m_ref
+    from r3m_amd import R3M
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    try:
+        host_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
+    except (ValueError, OSError):
+        host_gb = 0.0
+    if host_gb < 200:
+        pytest.skip(f"the CPU oracle at 1280 frames needs ~60 GB of host memory headroom; host has {host_gb:.0f} GB")
+    F = F_FULL
+    m = R3M("cuda", 1e-4, 1024, size=50, langweight=0.0, tcnweight=1.0)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict(shapes, "w").items()}
+    m.convnet.load_state_dict(sd)
+    m = m.to(DEV)
+    # 1280 DIFFERENT frames: 160 blocks of the hash generator (one 1280-frame call would allocate 3 x 1.5 GB of uint64 scratch)
+    x = torch.cat([torch.from_numpy(detgen.frames(f"bench{b}", (8, 3, 224, 224))) for b in range(F // 8)])
+    ref = r3m_ref.R3MRef(size=50, langweight=0.0, tcnweight=1.0)
+    ref.convnet.load_state_dict(sd)
+    ref.train()
+    torch.set_num_threads(max(1, min(64, (len(os.sched_getaffinity(0)) // 2) or 1)))
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        h_ref = ref(x).numpy()
+    t_cpu = time.time() - t0
+    m.train()
+    with torch.no_grad():
+        h = m(x.to(DEV)).cpu().numpy()
+    e_max, e_l2 = rel_err(h, h_ref)
+    print(f"r50 F={F} train forward vs the CPU oracle ({t_cpu:.0f} s on the host): embeddings max-rel {e_max:.3e} l2-rel {e_l2:.3e}")
+    assert e_max <= 1e-4
+    sdm, sdr = m.convnet.state_dict(), ref.convnet.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "layer1.0.bn3.running_var", "layer4.2.bn3.running_mean", "layer4.2.bn3.running_var"):
+        e = rel_err(sdm[k].cpu().numpy(), sdr[k].numpy())[0]
+        print(f"  {k}: max-rel {e:.3e}")
+        assert e < 1e-4, (k, e)
+    assert int(sdm["bn1.num_batches_tracked"]) == 1
+    del m, x
+    torch.cuda.empty_cache()

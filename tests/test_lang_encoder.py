@@ -75,3 +75,48 @@ def test_missing_pretrained_files_fail_with_a_clear_message():
     enc = LangEncoder("cpu", 0, 0)
     with pytest.raises(RuntimeError, match="precomputed"):
         enc(["open the drawer"])
+
+
+def _pretrained_distilbert():
+    """(tokenizer, model) of distilbert-base-uncased when the local HuggingFace cache holds it, else None (no network here)."""
+    try:
+        from transformers import AutoModel, AutoTokenizer
+        tok = AutoTokenizer.from_pretrained("distilbert-base-uncased", local_files_only=True)
+        model = AutoModel.from_pretrained("distilbert-base-uncased", local_files_only=True)
+        return tok, model.eval()
+    except Exception:  # noqa: BLE001  (OSError / EnvironmentError / ValueError depending on the transformers version)
+        return None
+
+
+def test_real_distilbert_when_it_is_in_the_local_cache():
+    """arms itself where `distilbert-base-uncased` exists in the local HF cache (skipped in this image, which
+    has neither the files nor a network). LangEncoder, loading the model by itself, must reproduce the reference formula
+    (/root/reference/r3m/models/models_language.py:29-34: tokenise with padding, one transformer pass under no_grad,
+    last_hidden_state.mean(1) over ALL positions) on the real weights, in both pooling modes."""
+    hf = _pretrained_distilbert()
+    if hf is None:
+        pytest.skip("distilbert-base-uncased is not in the local HuggingFace cache")
+    from r3m_amd.models_language import LangEncoder
+    tok, model = hf
+    sentences = ["open the drawer", "pick up the red cup and put it on the shelf next to the window", "c", "turn off the tap"]
+    with torch.no_grad():
+        enc_in = tok(sentences, return_tensors="pt", padding=True)
+        hidden = model(**enc_in).last_hidden_state
+        ref_all = hidden.mean(1)                                        # the reference: padding included
+        w = enc_in["attention_mask"].to(hidden.dtype).unsqueeze(-1)
+        ref_masked = (hidden * w).sum(1) / w.sum(1)
+    enc = LangEncoder("cpu", 0, 0)                                      # loads the SAME files itself (local_files_only)
+    got = enc(sentences)
+    assert got.shape == (4, 768) and not got.requires_grad and enc.encoder_calls == 1
+    assert rel_err(got.numpy(), ref_all.numpy())[0] < 1e-5
+    assert float((ref_all - ref_masked).abs().max()) > 1e-3              # the two poolings differ on a padded batch
+    got_m = LangEncoder("cpu", 0, 0, mask_padding=True)(sentences)
+    assert rel_err(got_m.numpy(), ref_masked.numpy())[0] < 1e-5
+    # batch-independence of the masked form; batch-dependence of the reference form (App. C quirk) on real weights
+    alone = LangEncoder("cpu", 0, 0, mask_padding=True)([sentences[0]])
+    assert rel_err(alone.numpy(), got_m[:1].numpy())[0] < 1e-4
+    alone_ref = LangEncoder("cpu", 0, 0)([sentences[0]])
+    assert float((alone_ref - got[:1]).abs().max()) > 1e-3
+    # frozen: stays in eval mode through model.train() (no dropout noise between the 15 get_reward calls of a step)
+    enc.train()
+    assert torch.equal(enc(sentences), got)

@@ -91,6 +91,44 @@ def test_oracle_full_step_matches_reference_golden(golden_dir):
     assert np.abs(sd["bn1.weight"].numpy() - g["post_bn1.weight"]).max() < 4.2e-4
 
 
+def test_oracle_matches_reference_on_the_kink_free_case(golden_dir):
+    """G8 (tests/golden/encoder_r18_nokink.npz): the oracle restatement in fp32 reproduces the reference's own fp32 forward and
+    gradient norms on the kink-free state, and in float64 the float64 vectors stored next to them; the case is kink-free."""
+    from oracle import detgen, r3m_ref
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "encoder_r18_nokink.npz"))
+    assert float(g["min_abs_z"]) > 1e-3 and 0.0 < float(g["frac_z_negative"]) < 0.01      # no kink, but the last ReLU is not trivial
+    m = r3m_ref.R3MRef(size=18, langweight=0.0, tcnweight=1.0)
+    shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
+    sd = detgen.resnet_state_dict_no_kink(shapes, 18, tag="nk2", shift=4.0)
+    m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    x = torch.from_numpy(detgen.frames("frames8nk", (8, 3, 224, 224)))
+    m.train()
+    h = m(x)
+    assert rel_err(h.detach().numpy(), g["h_train"])[0] < 1e-5
+    cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5))
+    (h * cw).sum().backward()
+    P = dict(m.convnet.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(float(P[str(name)].grad.double().norm()) - ref) <= 1e-3 * ref, name
+    # every golden file of the family is kink-free
+    for size in (34, 50):
+        assert float(np.load(os.path.join(golden_dir, f"encoder_r{size}_nokink.npz"))["min_abs_z"]) > 1e-3
+
+
+def test_oracle_full_step_r34_matches_reference_golden(golden_dir):
+    """G5 at ResNet-34 (full-step goldens for ResNet-34 / 50 at B = 2; the ResNet-50 file is checked on the GPU)."""
+    from oracle import detgen, r3m_ref
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "step_r34.npz"))
+    m = _ref_model(34, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    frames = torch.from_numpy(detgen.frames("stepframes", (2, 5, 3, 224, 224)))
+    names = [str(n) for n in g["metric_names"]]
+    met = r3m_ref.train_step_ref(m, frames, tcn_perm=torch.from_numpy(g["perms_0"]))
+    for k, v in zip(names, g["metric_values_0"]):
+        assert abs(met[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, met[k], v)
+
+
 def test_bf16_emulation_checker_is_sane():
     """oracle/bf16_emul.py (the checker of the mixed-precision encoder): it must actually round (differs from the exact
     float64 graph), stay at bf16 distance from it on a well-conditioned case (ResNet-18, eval-mode BatchNorm), keep weight
