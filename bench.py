@@ -385,10 +385,12 @@ def pmc_traffic(bf16, size, clips, dom_kernel):
     """HBM bytes per launch of the dominant class from the PMC passes (rocprofv3 --pmc cannot run inside this process): NOT
     measured in this run — read from the committed summary of the last counter run and labelled as such. The summary is only
     used when it describes THIS workload and THIS kernel class and its source file is still in the tree."""
-    pmc_name = "pmc_latest_bf16.json" if bf16 else "pmc_latest.json"
-    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-    if not os.path.exists(pmc_path):
+    # one summary per (precision, encoder size): pmc_latest[_bf16][_r<size>].json, the un-suffixed names being ResNet-50's
+    stem = "pmc_latest_bf16" if bf16 else "pmc_latest"
+    pmc_name = next((n for n in (f"{stem}_r{size}.json", f"{stem}.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if pmc_name is None:
         return None, None
+    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
     try:
         pj = json.load(open(pmc_path))
     except Exception as e:   # a broken summary must not take the bench line down with it

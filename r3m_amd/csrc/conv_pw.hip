@@ -15,18 +15,21 @@
 //   * operands arrive by `buffer_load_dwordx4 ... lds` through wave-uniform descriptors: per-lane offsets are kernel constants,
 //     the K position rides in the instruction's scalar offset, rows past M fall off the descriptor and land zeros — the K loop
 //     holds NO vector ALU instruction;
-//   * the epilogue works straight from the accumulators (32x32 MFMA result layout: a lane owns one COLUMN, its 16 registers are
-//     rows): a `buffer_store_dword` writes two full 128-byte row segments, its row offset is a scalar; BatchNorm partials (forward
-//     statistics, or the backward sums of EPI_BNRED) are in-lane sums over rows; residual-gradient / mask / y operands are read
-//     with the same descriptor arithmetic. No LDS slab, no per-store address arithmetic, no exec masks;
+//   * the epilogue takes BatchNorm forward statistics straight from the accumulators (32x32 MFMA result layout: a lane owns one
+//     COLUMN, its 16 registers are rows: in-lane sums) and stores through a 2 KB per-wave LDS slab, 8 rows at a time: 16
+//     `buffer_store_dwordx4` per wave tile through a descriptor, row offsets scalar, per-lane offsets constant — no address
+//     arithmetic, no exec masks. (Round 4 first stored the accumulators directly, 64 `buffer_store_dword` of two 128-byte row
+//     segments each and no LDS: tools/micro/storepat.hip shows a CU retires one store INSTRUCTION per 14-19 cycles whatever its
+//     width — 3.0 us of a wave's issue time per tile against 1.0 us for the 16 wide stores.)
 //   * read-modify-write epilogues (residual-gradient join, EPI_BNRED's y, EPI_ACCUM's old result) PREFETCH their operands into
 //     registers during the last two K steps of the tile, a few loads between every four MFMAs, so that the epilogue itself
 //     waits for nothing (measured with loads inside the epilogue: every sub-tile paid a full HBM latency and these launches ran
-//     5 % SLOWER than in the per-tile kernels whose four blocks per CU hide it). The 1-bit masks of a wave's 64 x 64 tile are ONE
-//     dwordx2 load (lane = row) expanded with ds_bpermute;
+//     5 % SLOWER than in the per-tile kernels whose four blocks per CU hide it); the operands arrive in the STORE layout (one
+//     dwordx4 per tensor and store). The 1-bit masks of a wave's 64 x 64 tile are ONE dwordx2 load (lane = row) expanded with
+//     ds_bpermute;
 //   * the epilogue of tile i is DEFERRED into the first K step of tile i + 1, after that step's data has landed and the
 //     following step's DMA is issued. gfx9 has ONE in-order counter for loads and stores: the wait that publishes the next LDS
-//     stage is `vmcnt(63)` there — the DMA is older than the 64 stores — so the stores are first waited for one further K step
+//     stage is `vmcnt(16)` there — the DMA is older than the 16 stores — so the stores are first waited for one further K step
 //     later, with the DMA of the step after that.
 #include "common.h"
 #include "conv_dev.h"
@@ -48,6 +51,21 @@ __device__ __forceinline__ unsigned pw_ldu(const void* base, int bytes, unsigned
   return __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, PW_RSRC_FLAGS), voff, soff, 0);
 #else
   return 0u;
+#endif
+}
+typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pw_ld4(const void* base, int bytes, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, PW_RSRC_FLAGS), voff, soff, 0));
+#else
+  return f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+}
+__device__ __forceinline__ void pw_st4(void* base, int bytes, unsigned voff, int soff, f32x4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pw_u32x4, v), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, PW_RSRC_FLAGS), voff,
+                                         soff, 0);
 #endif
 }
 typedef unsigned pw_u32x2 __attribute__((ext_vector_type(2)));
@@ -133,10 +151,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   constexpr bool MADD = (EPI & EPI_MASKED_ADD) != 0, BNR = (EPI & EPI_BNRED) != 0, ACC = (EPI & EPI_ACCUM) != 0;
   constexpr bool PRE = MADD || BNR || ACC;
   static_assert(!(MADD && ACC), "one added tensor");
-  const unsigned vo = (unsigned)(((wm * 64 + 4 * lh) * Nc + wn * 64 + lrow) * 4);           // per-lane element offset (bytes) in the tile
+  // Store layout (after the per-wave LDS transposition of the epilogue): a lane owns FOUR consecutive columns of one row; a
+  // dwordx4 instruction covers 4 rows x 64 columns. Store s = (tm, q, i) of 16 holds wave-tile rows tm 32 + 8 q + 4 i + (lane >> 4),
+  // columns 4 (lane & 15) .. +3. (Measured, tools/micro/storepat.hip: a CU retires ~1 store instruction per 14-19 cycles whatever
+  // its width, so 16 dwordx4 per wave tile cost a third of 64 dwords; the same goes for the operand loads.)
+  const int srow = lane >> 4, scol = (lane & 15) * 4;
+  const unsigned vo4 = (unsigned)(((wm * 64 + srow) * Nc + wn * 64 + scol) * 4);           // per-lane byte offset in the tile (constant)
   const int Nw = Nc >> 5;                                                                   // mask words per row
   const unsigned vow = (unsigned)(((wm * 64 + lane) * Nw + wn * 2) * 4);                    // mask words of row `lane`, this wave's columns
-  float pg[PRE ? 2 : 1][2][16], py[PRE ? 2 : 1][2][16];   // add0 (or the old result) and y of the tile, accumulator layout
+  f32x4 pg[PRE ? 16 : 1], py[PRE ? 16 : 1];               // add0 (or the old result) and y of the tile, store layout
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 pgm = {0u, 0u}, pym = {0u, 0u};                   // lane l: the two mask words of tile row wm 64 + l
   const float* t_gb = nullptr;                            // set per tile (scalars): operand bases at the tile origin + byte counts
@@ -156,23 +179,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
       if constexpr (BNR) { t_yb = p.bn_y + eo0; t_ybits = YBITS ? p.bn_bits + (eo0 >> 5) : nullptr; }
     }
   };
-  // piece pc of 16: the four rows r = 4 q .. 4 q + 3 of sub-tile (tm, tn), pc = (tm * 2 + tn) * 4 + q; piece 0 also the mask words
+  // piece pc of 16 = the operands of store pc (one dwordx4 load per tensor); piece 0 also fetches the mask words
   auto pre_piece = [&](auto pc_c) __attribute__((always_inline)) {
     if constexpr (PRE) {
       constexpr int pc = decltype(pc_c)::value;
-      constexpr int tm = pc >> 3, tn = (pc >> 2) & 1, q = pc & 3;
-      // the row stride is made opaque here so that the 64 scalar row offsets of a tile are s_mul'ed where they are used instead
-      // of being hoisted out of the tile loop (they do not fit the SGPR file: 230 spills, each reloaded with a v_readlane)
+      // the row stride is made opaque here so that the scalar row offsets of a tile are s_mul'ed where they are used instead of
+      // being hoisted out of the tile loop (they do not fit the SGPR file and would be reloaded with v_readlane)
       int ncb = Nc * 4;
       asm volatile("" : "+s"(ncb));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * q + e;
-        const int rr = tm * 32 + 8 * q + e;               // 8 (r >> 2) + (r & 3) with r = 4 q + e
-        const int so = rr * ncb + tn * 128;
-        if constexpr (MADD || ACC) pg[tm][tn][r] = pw_ld(t_gb, t_obytes, vo, so);
-        if constexpr (BNR) py[tm][tn][r] = pw_ld(t_yb, t_obytes, vo, so);
-      }
+      const int so = (pc * 4) * ncb;                      // rows tm 32 + 8 q + 4 i = 4 pc
+      if constexpr (MADD || ACC) pg[pc] = pw_ld4(t_gb, t_obytes, vo4, so);
+      if constexpr (BNR) py[pc] = pw_ld4(t_yb, t_obytes, vo4, so);
       if constexpr (pc == 0) {
         if constexpr (MADD) pgm = pw_ld2(t_gbits, t_bbytes, vow);
         if constexpr (BNR && YBITS) pym = pw_ld2(t_ybits, t_bbytes, vow);
@@ -246,9 +263,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     });
   };
 
-  // ---- epilogue, part 1 (stores + partial sums), straight from the accumulators of tile (emt, ent); read-modify-write
-  // operands are in pg / py / pgm / pym by now (their loads were waited for with the K step's DMA)
-  const int bp0 = 16 * lh;                                // ds_bpermute byte address of lane 4 lh (the row a lane half adds)
+  // ---- epilogue, part 1 (stores + partial sums) of tile (emt, ent). BatchNorm forward statistics come straight from the
+  // accumulators (a lane owns a column there: in-lane sums). The result leaves through a per-wave LDS slab of 8 rows x 64 columns
+  // (2 KB): the four registers r = 4 q .. 4 q + 3 of both column tiles are written (8 ds_write_b32, immediates only), read back as
+  // two float4 per lane and stored with two buffer_store_dwordx4 whose row offset is a scalar. A wave's LDS accesses execute in
+  // order, so the slab needs no barrier; read-modify-write operands are in pg / py / pgm / pym by now (their loads were waited
+  // for with the K step's DMA).
+  float* slab = smem + 2 * STAGE + WM * 2 * BN + wave_s * (8 * 64);
+  float* slab_w = slab + 4 * lh * 64 + lrow;              // + (e 64 + tn 32): element (row 4 lh + e, column tn 32 + lrow)
+  const float* slab_r = slab + srow * 64 + scol;          // + i 256: row 4 i + srow, columns scol .. +3
+  const int bp0 = 4 * srow;                               // ds_bpermute byte address of lane `srow` (+ 4 x the store's first row)
+  const bool hiw = (lane & 8) != 0;                       // the lane's columns lie in the second mask word of the wave's 64
+  const int nsh = (lane & 7) * 4;                         // ... at this bit
   auto epilogue1 = [&](int emt, int ent) __attribute__((always_inline)) {
     const int m0 = emt * BM, n0 = ent * BN;
     if (R3M_PROBE(p) & 4) return;                         // timing probes (probe builds only; wrong results)
@@ -278,60 +304,75 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     const long long eo0 = (long long)m0 * Nc + n0;                  // element offset of the tile origin
     const int obytes = ((rows_valid - 1) * Nc + BN) * 4;            // a lane's offset is inside iff its row is < rows_valid
     float* ob = p.out + eo0;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, mu[2] = {0.f, 0.f}, sc[2] = {0.f, 0.f}, sh[2] = {0.f, 0.f};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, sc = s1, sh = s1;
     if constexpr (BNR) {
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + wn * 64 + tn * 32 + lrow;
-        mu[tn] = p.bn_mean[col];
-        if constexpr (!YBITS) { sc[tn] = p.bn_scale[col]; sh[tn] = p.bn_shift[col]; }
+      const int col = n0 + wn * 64 + scol;
+      mu = *reinterpret_cast<const f32x4*>(p.bn_mean + col);
+      if constexpr (!YBITS) {
+        sc = *reinterpret_cast<const f32x4*>(p.bn_scale + col);
+        sh = *reinterpret_cast<const f32x4*>(p.bn_shift + col);
       }
     }
+    static_for<8>([&](auto c_c) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value;             // chunk (tm, q): wave-tile rows 8 c .. 8 c + 7
+      constexpr int tm = c >> 2, q = c & 3;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        int ncb = Nc * 4;
-        asm volatile("" : "+s"(ncb));                     // see pre_piece: row offsets computed at the point of use
+        for (int e = 0; e < 4; ++e) slab_w[e * 64 + tn * 32] = acc[tm][tn][4 * q + e];
+      __builtin_amdgcn_wave_barrier();
+      int ncb = Nc * 4;
+      asm volatile("" : "+s"(ncb));                       // see pre_piece: row offsets computed at the point of use
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = tm * 32 + 8 * (r >> 2) + (r & 3);
-          const int so = rr * ncb + tn * 128;
-          float v = acc[tm][tn][r];
-          if constexpr (ACC) v += pg[tm][tn][r];
-          if constexpr (MADD) {
-            const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + rr * 4, (int)pgm[tn]);   // mask word of this element's row
-            v += ((w >> lrow) & 1u) ? pg[tm][tn][r] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int st = c * 2 + i;                         // store index 0..15: rows 4 st + srow
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab_r + i * 256);
+        if constexpr (ACC) v += pg[st];
+        if constexpr (MADD) {
+          const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pgm[0]);
+          const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pgm[1]);
+          const unsigned nb = ((hiw ? w1 : w0) >> nsh) & 15u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? pg[st][e] : 0.f;
+        }
+        if (!(R3M_PROBE(p) & 1)) pw_st4(ob, obytes, vo4, (st * 4) * ncb, v);
+        if constexpr (BNR) {
+          const f32x4 y = py[st];
+          unsigned nb = 0u;
+          if constexpr (YBITS) {
+            const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pym[0]);
+            const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pym[1]);
+            nb = ((hiw ? w1 : w0) >> nsh) & 15u;
           }
-          if (!(R3M_PROBE(p) & 1)) pw_st(ob, obytes, vo, so, v);
-          if constexpr (BNR) {
-            const float y = py[tm][tn][r];
-            bool on;
-            if constexpr (YBITS) {
-              const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + rr * 4, (int)pym[tn]);
-              on = ((w >> lrow) & 1u) != 0u;
-            } else {
-              on = fmaf(y, sc[tn], sh[tn]) > 0.f;
-            }
-            const float gg = on ? v : 0.f;
-            s1[tn] += gg;
-            s2[tn] = fmaf(gg, y - mu[tn], s2[tn]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool on = YBITS ? (((nb >> e) & 1u) != 0u) : (fmaf(y[e], sc[e], sh[e]) > 0.f);
+            const float gg = on ? v[e] : 0.f;
+            s1[e] += gg;
+            s2[e] = fmaf(gg, y[e] - mu[e], s2[e]);
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();                    // the chunk's slab reads are issued before the next chunk's writes
+    });
     if constexpr (BNR) {
-      // the wave's 64 rows are one partial row of the consumer BatchNorm's backward sums (geometry of bnred_partial_rows)
+      // the wave's 64 rows are one partial row of the consumer BatchNorm's backward sums (geometry of bnred_partial_rows):
+      // lanes l, l + 16, l + 32, l + 48 hold the same four columns
       const int g0 = m0 + wm * 64;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        s1[tn] += __shfl_xor(s1[tn], 32);
-        s2[tn] += __shfl_xor(s2[tn], 32);
-        if (lane < 32 && g0 < p.M) {
-          const long long prow = g0 >> 6;
-          const int col = n0 + wn * 64 + tn * 32 + lane;
-          p.stats[(prow * 2 + 0) * Nc + col] = s1[tn];
-          p.stats[(prow * 2 + 1) * Nc + col] = s2[tn];
-        }
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += __shfl_xor(s1[e], 16);
+        s2[e] += __shfl_xor(s2[e], 16);
+        s1[e] += __shfl_xor(s1[e], 32);
+        s2[e] += __shfl_xor(s2[e], 32);
+      }
+      if (lane < 16 && g0 < p.M) {
+        const long long prow = g0 >> 6;
+        const int col = n0 + wn * 64 + scol;
+        *reinterpret_cast<f32x4*>(p.stats + (prow * 2 + 0) * Nc + col) = s1;
+        *reinterpret_cast<f32x4*>(p.stats + (prow * 2 + 1) * Nc + col) = s2;
       }
     }
   };
@@ -391,14 +432,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
         kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
       }
       // The counter is in order over loads AND stores on gfx9 (no separate store counter; the compiler's own waits rely on it):
-      // right after a deferred epilogue the 64 stores of this wave are YOUNGER than the DMA this step needs, so "all but the 63
-      // most recent" = that DMA (+ one store) — the stores keep flying under this step's MFMAs instead of being waited for here
-      // (timing probe: with the stores removed the K = 64 launch runs 1.20 instead of 1.61 ms; their L2 acknowledgement under a
-      // 2.6 TB/s write load takes longer than the 64 MFMAs that used to separate issue and wait).
+      // right after a deferred epilogue the 16 stores of this wave are YOUNGER than the DMA this step needs, so "all but the 16
+      // most recent" covers that DMA — the stores keep flying under this step's MFMAs instead of being waited for here.
       // (__syncthreads() carries a workgroup-scope release fence = vmcnt(0); the hand-off here is LDS only — DMA landed per wave,
       // `red` written with lgkmcnt(0) — so a bare s_barrier is enough.)
       if (pr == 0 && pending && !(R3M_PROBE(p) & (1 | 4 | 16))) {
-        asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -459,7 +498,7 @@ int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(tiles_ll < 0x7FFFFFFFLL, "pw_gemm: too many tiles");
   const int tiles = (int)tiles_ll;
   const int W = tiles < 2 * pw_cu_count() ? tiles : 2 * pw_cu_count();
-  constexpr int LDS = (2 * (BM + BN) * 32 + 2 * 2 * BN) * 4;
+  constexpr int LDS = (2 * (BM + BN) * 32 + 2 * 2 * BN + 4 * 8 * 64) * 4;   // ring + statistics scratch + four 2 KB store slabs
 #define LAUNCH_PW(E, YB)                                                                                                          \
   do {                                                                                                                           \
     static DynLdsOptIn oi;                                                                                                       \

@@ -56,6 +56,7 @@ def group(k):
     k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<128, 128, 2, 2, \d+(, \d+)*>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"gather_gemm(_glds2?|_bf16)?_kernel<256, 64, 4, 1, \d+(, \d+)*>", "gather_gemm 256x64 (all epilogues)", k)
     k = re.sub(r"gather_gemm_k16_kernel<\d+>", "gather_gemm 128x128 (all epilogues)", k)      # 16-wide-K variant of the same tile (round 2)
+    k = re.sub(r"pw_gemm_kernel<128, 128, 2, 2, \d+(, \w+)*>", "gather_gemm 128x128 (all epilogues)", k)   # persistent 1x1 kernel (round 4): same launch class
     # the window / halo kernels' launches belong to the same launch classes as the gather kernel's (bench.py's roofline classes)
     k = re.sub(r"conv3x3_win_kernel<128, 128, 2, 2, \d+, \d+>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"conv3x3_halo_bf16_kernel<(128|256), 128, 2, 2, \d+>", "gather_gemm 128x128 (all epilogues)", k)
