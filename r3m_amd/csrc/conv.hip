@@ -1011,6 +1011,12 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // 1x1 / stride 1, 64-wide output: persistent kernel, eight-wave 256 x 64 tile
+      if (int e = launch_pw_gemm(p, s)) return e;
+      prof_bytes(gather_gemm_alg_bytes(p, 4));
+      prof_end(s);
+      return check_launch("pw_gemm");
+    }
     if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
 #define LAUNCH_NARROW2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<256, 64, 4, 1, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_NARROW2)

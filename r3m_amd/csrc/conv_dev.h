@@ -45,6 +45,14 @@ __device__ __forceinline__ void buf_store16(void* base, int bytes, unsigned voff
   __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), voff, 0, R3M_EPI_NT ? 2 : 0);
 #endif
 }
+// 16-byte load through a buffer descriptor: lanes whose offset is past the end read zeros
+__device__ __forceinline__ epi_u32x4 buf_load16(const void* base, int bytes, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), voff, 0, 0);
+#else
+  return epi_u32x4{0u, 0u, 0u, 0u};
+#endif
+}
 __device__ __forceinline__ void st8_out(bf16_t* p, bf16x8 v) {
 #if R3M_EPI_NT
   __builtin_nontemporal_store(__builtin_bit_cast(epi_u32x4, v), reinterpret_cast<epi_u32x4*>(p));
@@ -359,8 +367,9 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
     bnacc.clear();
     bncoef.load(p, gcol);
   }
-  auto bnred8 = [&](const bf16x8 dzv, long long eo) __attribute__((always_inline)) {
-    const bf16x8 yv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bn_y) + eo);
+  // y of the BatchNorm is requested for all rows of a pass BEFORE the pass's stores (a load cannot move above an earlier store,
+  // so loading it next to its use made every store instruction wait a full memory latency — round 4)
+  auto bnred8 = [&](const bf16x8 dzv, const bf16x8 yv, long long eo) __attribute__((always_inline)) {
     float dz[8], yy[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dz[e] = (float)dzv[e]; yy[e] = (float)yv[e]; }
@@ -392,7 +401,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
             slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[ps * TMP + tm][tn][r];
       __builtin_amdgcn_wave_barrier();
       bool stored = false;
-      if constexpr ((EPI & EPI_BNRED) == 0) {
+      {
         // Contiguous output rows (every forward, stride-1 dgrad): the wave's 64 rows go out through a buffer descriptor that starts
         // at its first row and ends with the tensor — a lane's address is a 32-bit offset advanced by one add per store, rows past
         // M fall off the descriptor's end. (The generic path below costs a 64-bit multiply-add, a compare and an exec mask per
@@ -404,10 +413,20 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
           const int rbytes = left < (long long)BUF_OOB ? (int)left : (int)BUF_OOB;
           unsigned voff = gcol < p.Nc ? (unsigned)((erow * p.Nc + gcol) * 2) : BUF_OOB;
           const unsigned vstep = (unsigned)(RPI * p.Nc * 2);
+          constexpr int NITP = TMP * 32 / RPI;
+          bf16x8 ypre[(EPI & EPI_BNRED) ? NITP : 1];
+          if constexpr ((EPI & EPI_BNRED) != 0) {        // EPI_BNRED (round 4): y of the whole pass through the same offsets, before the stores
+            const bf16_t* ybase = reinterpret_cast<const bf16_t*>(p.bn_y) + (long long)rowbase * p.Nc;
 #pragma unroll
-          for (int it = 0; it < TMP * 32 / RPI; ++it) {
+            for (int it = 0; it < NITP; ++it) ypre[it] = __builtin_bit_cast(bf16x8, buf_load16(ybase, rbytes, voff + it * vstep));
+          }
+#pragma unroll
+          for (int it = 0; it < NITP; ++it) {
             const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + (it * RPI + erow) * CSH + ecol);
             buf_store16(rbase, rbytes, voff, __builtin_bit_cast(epi_u32x4, ov));
+            if constexpr ((EPI & EPI_BNRED) != 0) {
+              if (voff < (unsigned)rbytes) bnred8(ov, ypre[it], (long long)rowbase * p.Nc + (voff >> 1));   // rows past M hold no mask bits
+            }
             voff += vstep;
           }
           stored = true;
@@ -415,15 +434,25 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
         if (out_simple) stored = true;       // rowbase >= M: nothing of this pass is inside the tensor
       }
       if (!stored) {
+        constexpr int NITP = TMP * 32 / RPI;
+        bf16x8 ypre[(EPI & EPI_BNRED) ? NITP : 1];
+        if constexpr ((EPI & EPI_BNRED) != 0) {
 #pragma unroll
-        for (int it = 0; it < TMP * 32 / RPI; ++it) {
+          for (int it = 0; it < NITP; ++it) {
+            const int row = m0 + (wm * TM + ps * TMP) * 32 + it * RPI + erow;
+            if (row < p.M && gcol < p.Nc)
+              ypre[it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bn_y) + row_off(row) + gcol);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < NITP; ++it) {
           const int lr = it * RPI + erow;
           const int row = m0 + (wm * TM + ps * TMP) * 32 + lr;
           if (row < p.M && gcol < p.Nc) {
             const bf16x8 ov = *reinterpret_cast<const bf16x8*>(slab + lr * CSH + ecol);
             const long long eo = row_off(row) + gcol;
             st8_out(outp + eo, ov);
-            if constexpr ((EPI & EPI_BNRED) != 0) bnred8(ov, eo);
+            if constexpr ((EPI & EPI_BNRED) != 0) bnred8(ov, ypre[it], eo);
           }
         }
       }
@@ -447,7 +476,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
       __builtin_amdgcn_wave_barrier();
       // operands of the tile's rows requested before any of its stores (see gg_epilogue: loads cannot move above earlier stores)
       constexpr int NIT = 32 / RPI;
-      bf16x8 opre[NIT], gpre[NIT];
+      bf16x8 opre[NIT], gpre[NIT], ypre[NIT];
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
         const int rowq = m0 + (wm * TM + tm) * 32 + q * RPI + erow;
@@ -455,6 +484,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
           const long long eq = row_off(rowq) + gcol;
           if constexpr ((EPI & EPI_ACCUM) != 0) opre[q] = *reinterpret_cast<const bf16x8*>(outp + eq);
           if constexpr ((EPI & EPI_MASKED_ADD) != 0) gpre[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.add0) + eq);
+          if constexpr ((EPI & EPI_BNRED) != 0) ypre[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(p.bn_y) + eq);
         }
       }
 #pragma unroll
@@ -489,7 +519,7 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
           st8_out(outp + eo, o);
-          if constexpr ((EPI & EPI_BNRED) != 0) bnred8(o, eo);
+          if constexpr ((EPI & EPI_BNRED) != 0) bnred8(o, ypre[it], eo);
         }
       }
       __builtin_amdgcn_wave_barrier();

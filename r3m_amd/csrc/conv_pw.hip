@@ -85,12 +85,17 @@ __device__ __forceinline__ void pw_st(void* base, int bytes, unsigned voff, int 
 
 // EPI: 0, EPI_STATS, EPI_ACCUM, EPI_MASKED_ADD (1-bit mask only), EPI_BNRED, EPI_BNRED | EPI_MASKED_ADD
 // YBITS (EPI_BNRED): the consumer BatchNorm's ReLU mask comes as bits (block outputs) / is recomputed from y (inner BatchNorms)
+// Two shapes: <128, 128, 2, 2> — four waves of 64 x 64, two blocks per CU — for outputs whose width is a multiple of 128, and
+// <256, 64, 4, 2> — EIGHT waves of 64 x 32 (TN = 1), one block per CU — for the 64-channel outputs (conv1 / the dgrad of conv3 in
+// layer1): the 256-row tile keeps the statistics partial-row geometry of the other 64-wide kernels (gather_gemm_grid_m).
 template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false>
-__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
-  static_assert(BM / WM == 64 && BN / WN == 64 && WM * WN == 4, "wave tile is 64 x 64");
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
+  constexpr int NW = WM * WN, TN = BN / WN / 32;        // waves; 32-column MFMA tiles per wave (2 or 1)
+  static_assert(BM / WM == 64 && (TN == 1 || TN == 2) && (NW == 4 || NW == 8), "wave tile is 64 rows x 32 TN columns");
   constexpr int STAGE = (BM + BN) * 32;                 // floats per stage: {A[BM][32], B[BN][32]}, 128-byte rows
-  constexpr int AJ = BM / 32, BJ = BN / 32, NP = AJ + BJ;
-  static_assert(NP == 8 || NP == 10, "piece schedule assumes 8 (128x128) or 10 (256x64) pieces");
+  constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW), NP = AJ + BJ;   // DMA pieces (8 rows each) per wave and stage
+  static_assert(AJ >= 1 && BJ >= 1 && NP <= 8, "a wave stages whole DMA instructions, at most one per odd MFMA slot");
+  constexpr int NST = 8 * TN;                           // dwordx4 stores per wave tile (a store covers 64 / (8 TN) rows)
   extern __shared__ __attribute__((aligned(128))) float smem[];
   float* red = smem + 2 * STAGE;                        // [WM][2][BN]: BatchNorm statistics of the wave rows (EPI_STATS)
 
@@ -101,19 +106,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   const int K = p.Ci, Nc = p.Nc, Kb = K * 4;
   const int lrow = lane & 31, lh = lane >> 5;
 
-  // ---- DMA: wave w stages rows [w BM/4, +BM/4) of A and [w BN/4, +BN/4) of B, 8 rows (1 KiB) per instruction; the 16-byte
+  // ---- DMA: wave w stages rows [w BM/NW, +BM/NW) of A and [w BN/NW, +BN/NW) of B, 8 rows (1 KiB) per instruction; the 16-byte
   // slot a lane fetches is XOR-swizzled by (row >> 1) & 7 (conv.hip, glds2 kernel). Offsets are constants of the kernel.
   unsigned voffA[AJ], voffB[BJ];
   {
     const int srow = lane >> 3, pslot = lane & 7;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int r = wave_s * (BM / 4) + j * 8 + srow;
+      const int r = wave_s * (BM / NW) + j * 8 + srow;
       voffA[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int r = wave_s * (BN / 4) + j * 8 + srow;
+      const int r = wave_s * (BN / NW) + j * 8 + srow;
       voffB[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
     }
   }
@@ -121,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     constexpr int STG = decltype(stg_c)::value, pc = decltype(pc_c)::value;
     if (R3M_PROBE(p) & 8) return;                         // timing probe: no DMA (stale LDS)
     if constexpr (pc < AJ)
-      buf_dma16(ab, abytes, smem + STG * STAGE + wave_s * (BM / 4) * 32 + pc * 8 * 32, voffA[pc], soff);
+      buf_dma16(ab, abytes, smem + STG * STAGE + wave_s * (BM / NW) * 32 + pc * 8 * 32, voffA[pc], soff);
     else
-      buf_dma16(bb, BN * Kb, smem + STG * STAGE + BM * 32 + wave_s * (BN / 4) * 32 + (pc - AJ) * 8 * 32, voffB[pc - AJ], soff);
+      buf_dma16(bb, BN * Kb, smem + STG * STAGE + BM * 32 + wave_s * (BN / NW) * 32 + (pc - AJ) * 8 * 32, voffB[pc - AJ], soff);
   };
   auto dma_all = [&](auto stg_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
     static_for<NP>([&](auto pc_c) __attribute__((always_inline)) { dma_piece(stg_c, pc_c, ab, abytes, bb, soff); });
@@ -141,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     for (int g = 0; g < 4; ++g) {
       const int go = ((2 * g + lh) ^ xr) * 4;
       fa[g] = smem + (wm * 64 + lrow) * 32 + go;
-      fb[g] = smem + BM * 32 + (wn * 64 + lrow) * 32 + go;
+      fb[g] = smem + BM * 32 + (wn * TN * 32 + lrow) * 32 + go;
     }
   }
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 
   // ---- epilogue operands of the tile being computed, prefetched into registers (read-modify-write epilogues only)
   // acc[tm][tn][r] is row m0 + wm 64 + tm 32 + 8 (r >> 2) + 4 lh + (r & 3), column n0 + wn 64 + tn 32 + lrow.
@@ -155,11 +160,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   // dwordx4 instruction covers 4 rows x 64 columns. Store s = (tm, q, i) of 16 holds wave-tile rows tm 32 + 8 q + 4 i + (lane >> 4),
   // columns 4 (lane & 15) .. +3. (Measured, tools/micro/storepat.hip: a CU retires ~1 store instruction per 14-19 cycles whatever
   // its width, so 16 dwordx4 per wave tile cost a third of 64 dwords; the same goes for the operand loads.)
-  const int srow = lane >> 4, scol = (lane & 15) * 4;
-  const unsigned vo4 = (unsigned)(((wm * 64 + srow) * Nc + wn * 64 + scol) * 4);           // per-lane byte offset in the tile (constant)
+  constexpr int LPR = 8 * TN, RPS = 64 / LPR;             // lanes per row of a store, rows per store (TN = 2: 16, 4; TN = 1: 8, 8)
+  const int srow = lane / LPR, scol = (lane % LPR) * 4;
+  const unsigned vo4 = (unsigned)(((wm * 64 + srow) * Nc + wn * TN * 32 + scol) * 4);      // per-lane byte offset in the tile (constant)
   const int Nw = Nc >> 5;                                                                   // mask words per row
-  const unsigned vow = (unsigned)(((wm * 64 + lane) * Nw + wn * 2) * 4);                    // mask words of row `lane`, this wave's columns
-  f32x4 pg[PRE ? 16 : 1], py[PRE ? 16 : 1];               // add0 (or the old result) and y of the tile, store layout
+  const unsigned vow = (unsigned)(((wm * 64 + lane) * Nw + wn * TN) * 4);                   // mask word(s) of row `lane`, this wave's columns
+  f32x4 pg[PRE ? NST : 1], py[PRE ? NST : 1];             // add0 (or the old result) and y of the tile, store layout
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 pgm = {0u, 0u}, pym = {0u, 0u};                   // lane l: the two mask words of tile row wm 64 + l
   const float* t_gb = nullptr;                            // set per tile (scalars): operand bases at the tile origin + byte counts
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
       if constexpr (BNR) { t_yb = p.bn_y + eo0; t_ybits = YBITS ? p.bn_bits + (eo0 >> 5) : nullptr; }
     }
   };
-  // piece pc of 16 = the operands of store pc (one dwordx4 load per tensor); piece 0 also fetches the mask words
+  // piece pc of NST = the operands of store pc (one dwordx4 load per tensor); piece 0 also fetches the mask words
   auto pre_piece = [&](auto pc_c) __attribute__((always_inline)) {
     if constexpr (PRE) {
       constexpr int pc = decltype(pc_c)::value;
@@ -187,12 +193,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
       // being hoisted out of the tile loop (they do not fit the SGPR file and would be reloaded with v_readlane)
       int ncb = Nc * 4;
       asm volatile("" : "+s"(ncb));
-      const int so = (pc * 4) * ncb;                      // rows tm 32 + 8 q + 4 i = 4 pc
+      const int so = (pc * RPS) * ncb;                    // first row of store pc
       if constexpr (MADD || ACC) pg[pc] = pw_ld4(t_gb, t_obytes, vo4, so);
       if constexpr (BNR) py[pc] = pw_ld4(t_yb, t_obytes, vo4, so);
       if constexpr (pc == 0) {
-        if constexpr (MADD) pgm = pw_ld2(t_gbits, t_bbytes, vow);
-        if constexpr (BNR && YBITS) pym = pw_ld2(t_ybits, t_bbytes, vow);
+        if constexpr (MADD) {
+          if constexpr (TN == 2) pgm = pw_ld2(t_gbits, t_bbytes, vow);
+          else pgm[0] = pw_ldu(t_gbits, t_bbytes, vow, 0);
+        }
+        if constexpr (BNR && YBITS) {
+          if constexpr (TN == 2) pym = pw_ld2(t_ybits, t_bbytes, vow);
+          else pym[0] = pw_ldu(t_ybits, t_bbytes, vow, 0);
+        }
       }
     }
   };
@@ -207,13 +219,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     // fragments of group g + 1 are requested before the MFMAs of group g (two register sets; one where the prefetched epilogue
     // operands of EPI_BNRED | EPI_MASKED_ADD leave no room: 64 accumulators + 128 operands)
     constexpr int FB = (MADD && BNR) ? 1 : 2;
-    f32x4 af[FB][2], bf[FB][2];
+    f32x4 af[FB][2], bf[FB][TN];
     auto frag_load = [&](auto g_c) __attribute__((always_inline)) {
       constexpr int g = decltype(g_c)::value;
 #pragma unroll
       for (int t = 0; t < 2; ++t) af[g % FB][t] = *reinterpret_cast<const f32x4*>(fa[g] + STG_M * STAGE + t * 32 * 32);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bf[g % FB][t] = *reinterpret_cast<const f32x4*>(fb[g] + STG_M * STAGE + t * 32 * 32);
+      for (int t = 0; t < TN; ++t) bf[g % FB][t] = *reinterpret_cast<const f32x4*>(fb[g] + STG_M * STAGE + t * 32 * 32);
     };
     if constexpr (FB == 2) frag_load(std::integral_constant<int, 0>{});
     static_for<4>([&](auto g_c) __attribute__((always_inline)) {
@@ -221,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
       if constexpr (FB == 1) frag_load(g_c);
       if constexpr (FB == 2 && g < 3) frag_load(std::integral_constant<int, g + 1>{});
       const f32x4(&a)[2] = af[g % FB];
-      const f32x4(&b)[2] = bf[g % FB];
+      const f32x4(&b)[TN] = bf[g % FB];
       static_for<4>([&](auto j_c) __attribute__((always_inline)) {
         constexpr int j = decltype(j_c)::value;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
+          for (int tn = 0; tn < TN; ++tn) {
             if constexpr (FIRST && g == 0 && j == 0) {
               const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], z, 0, 0, 0);
@@ -236,21 +248,21 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
             }
           }
         if constexpr (PRE && PF != 0) {
-          // slot s of this step carries operand piece (PF - 1) * 8 + s / 2 (even slots; the DMA pieces ride on the odd ones)
+          // slot s of this step carries operand piece (PF - 1) * NST / 2 + s / 2 (even slots; the DMA pieces ride on the odd ones)
           constexpr int slot = g * 4 + j;
-          if constexpr ((slot & 1) == 0) {
+          if constexpr ((slot & 1) == 0 && (slot >> 1) < NST / 2) {
             if (do_pf) {
               __builtin_amdgcn_sched_barrier(0);
-              pre_piece(std::integral_constant<int, (PF - 1) * 8 + (slot >> 1)>{});
+              pre_piece(std::integral_constant<int, (PF - 1) * (NST / 2) + (slot >> 1)>{});
               __builtin_amdgcn_sched_barrier(0);
             }
           }
         }
         if constexpr (DMA) {
-          // 16 slots of 4 MFMAs; 8 pieces: every second slot; 10 pieces: slots 0..11 except 5 and 11
+          // 16 slots of 2 TN MFMAs; piece k rides on odd slot 2 k + 1
           constexpr int slot = g * 4 + j;
-          constexpr bool fire = (NP == 8) ? ((slot & 1) == 1) : (slot < 12 && (slot % 6) != 5);
-          constexpr int piece = (NP == 8) ? (slot >> 1) : (slot - (slot > 5 ? 1 : 0));
+          constexpr bool fire = (slot & 1) == 1 && (slot >> 1) < NP;
+          constexpr int piece = slot >> 1;
           if constexpr (fire) {
             if (do_dma) {
               __builtin_amdgcn_sched_barrier(0);
@@ -269,19 +281,29 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
   // two float4 per lane and stored with two buffer_store_dwordx4 whose row offset is a scalar. A wave's LDS accesses execute in
   // order, so the slab needs no barrier; read-modify-write operands are in pg / py / pgm / pym by now (their loads were waited
   // for with the K step's DMA).
-  float* slab = smem + 2 * STAGE + WM * 2 * BN + wave_s * (8 * 64);
-  float* slab_w = slab + 4 * lh * 64 + lrow;              // + (e 64 + tn 32): element (row 4 lh + e, column tn 32 + lrow)
-  const float* slab_r = slab + srow * 64 + scol;          // + i 256: row 4 i + srow, columns scol .. +3
+  constexpr int CW = TN * 32;                             // columns of a wave tile = floats per slab row
+  float* slab = smem + 2 * STAGE + WM * 2 * BN + wave_s * (8 * CW);
+  float* slab_w = slab + 4 * lh * CW + lrow;              // + (e CW + tn 32): element (row 4 lh + e, column tn 32 + lrow)
+  const float* slab_r = slab + srow * CW + scol;          // + i RPS CW: row i RPS + srow, columns scol .. +3
   const int bp0 = 4 * srow;                               // ds_bpermute byte address of lane `srow` (+ 4 x the store's first row)
-  const bool hiw = (lane & 8) != 0;                       // the lane's columns lie in the second mask word of the wave's 64
+  const bool hiw = TN == 2 && (lane & 8) != 0;            // the lane's columns lie in the second mask word of the wave's 64
   const int nsh = (lane & 7) * 4;                         // ... at this bit
+  auto mask_nibble = [&](const u32x2& words, int st) __attribute__((always_inline)) -> unsigned {
+    const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * RPS * 4, (int)words[0]);   // mask word(s) of the store's row
+    unsigned w = w0;
+    if constexpr (TN == 2) {
+      const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * RPS * 4, (int)words[1]);
+      w = hiw ? w1 : w0;
+    }
+    return (w >> nsh) & 15u;
+  };
   auto epilogue1 = [&](int emt, int ent) __attribute__((always_inline)) {
     const int m0 = emt * BM, n0 = ent * BN;
     if (R3M_PROBE(p) & 4) return;                         // timing probes (probe builds only; wrong results)
     if ((EPI & EPI_STATS) != 0 && !(R3M_PROBE(p) & 2)) {
       // same summation order as gg_stats (conv_dev.h): rows >= M were staged as zeros and add nothing
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
+      for (int tn = 0; tn < TN; ++tn) {
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
         s += __shfl_xor(s, 32);
         ss += __shfl_xor(ss, 32);
         if (lane < 32) {
-          const int c = (wn * 2 + tn) * 32 + lane;
+          const int c = (wn * TN + tn) * 32 + lane;
           red[(wm * 2 + 0) * BN + c] = s;
           red[(wm * 2 + 1) * BN + c] = ss;
         }
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     float* ob = p.out + eo0;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, sc = s1, sh = s1;
     if constexpr (BNR) {
-      const int col = n0 + wn * 64 + scol;
+      const int col = n0 + wn * CW + scol;
       mu = *reinterpret_cast<const f32x4*>(p.bn_mean + col);
       if constexpr (!YBITS) {
         sc = *reinterpret_cast<const f32x4*>(p.bn_scale + col);
@@ -317,35 +339,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
       constexpr int c = decltype(c_c)::value;             // chunk (tm, q): wave-tile rows 8 c .. 8 c + 7
       constexpr int tm = c >> 2, q = c & 3;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) slab_w[e * 64 + tn * 32] = acc[tm][tn][4 * q + e];
+        for (int e = 0; e < 4; ++e) slab_w[e * CW + tn * 32] = acc[tm][tn][4 * q + e];
       __builtin_amdgcn_wave_barrier();
       int ncb = Nc * 4;
       asm volatile("" : "+s"(ncb));                       // see pre_piece: row offsets computed at the point of use
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int st = c * 2 + i;                         // store index 0..15: rows 4 st + srow
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab_r + i * 256);
+      for (int i = 0; i < TN; ++i) {                      // TN stores of RPS rows each cover the chunk's 8 rows
+        const int st = c * TN + i;                        // store index 0 .. NST - 1: rows st RPS + srow
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab_r + i * RPS * CW);
         if constexpr (ACC) v += pg[st];
         if constexpr (MADD) {
-          const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pgm[0]);
-          const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pgm[1]);
-          const unsigned nb = ((hiw ? w1 : w0) >> nsh) & 15u;
+          const unsigned nb = mask_nibble(pgm, st);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? pg[st][e] : 0.f;
         }
-        if (!(R3M_PROBE(p) & 1)) pw_st4(ob, obytes, vo4, (st * 4) * ncb, v);
+        if (!(R3M_PROBE(p) & 1)) pw_st4(ob, obytes, vo4, (st * RPS) * ncb, v);
         if constexpr (BNR) {
           const f32x4 y = py[st];
           unsigned nb = 0u;
-          if constexpr (YBITS) {
-            const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pym[0]);
-            const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp0 + st * 16, (int)pym[1]);
-            nb = ((hiw ? w1 : w0) >> nsh) & 15u;
-          }
+          if constexpr (YBITS) nb = mask_nibble(pym, st);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool on = YBITS ? (((nb >> e) & 1u) != 0u) : (fmaf(y[e], sc[e], sh[e]) > 0.f);
@@ -359,18 +373,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
     });
     if constexpr (BNR) {
       // the wave's 64 rows are one partial row of the consumer BatchNorm's backward sums (geometry of bnred_partial_rows):
-      // lanes l, l + 16, l + 32, l + 48 hold the same four columns
+      // lanes l, l + LPR, l + 2 LPR, ... hold the same four columns
       const int g0 = m0 + wm * 64;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s1[e] += __shfl_xor(s1[e], 16);
-        s2[e] += __shfl_xor(s2[e], 16);
-        s1[e] += __shfl_xor(s1[e], 32);
-        s2[e] += __shfl_xor(s2[e], 32);
-      }
-      if (lane < 16 && g0 < p.M) {
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          s1[e] += __shfl_xor(s1[e], o);
+          s2[e] += __shfl_xor(s2[e], o);
+        }
+      if (lane < LPR && g0 < p.M) {
         const long long prow = g0 >> 6;
-        const int col = n0 + wn * 64 + scol;
+        const int col = n0 + wn * CW + scol;
         *reinterpret_cast<f32x4*>(p.stats + (prow * 2 + 0) * Nc + col) = s1;
         *reinterpret_cast<f32x4*>(p.stats + (prow * 2 + 1) * Nc + col) = s2;
       }
@@ -432,12 +446,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GatherGemmParams 
         kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
       }
       // The counter is in order over loads AND stores on gfx9 (no separate store counter; the compiler's own waits rely on it):
-      // right after a deferred epilogue the 16 stores of this wave are YOUNGER than the DMA this step needs, so "all but the 16
-      // most recent" covers that DMA — the stores keep flying under this step's MFMAs instead of being waited for here.
+      // right after a deferred epilogue the NST (16 or 8) stores of this wave are YOUNGER than the DMA this step needs, so "all but
+      // the NST most recent" covers that DMA — the stores keep flying under this step's MFMAs instead of being waited for here.
       // (__syncthreads() carries a workgroup-scope release fence = vmcnt(0); the hand-off here is LDS only — DMA landed per wave,
       // `red` written with lgkmcnt(0) — so a bare s_barrier is enough.)
       if (pr == 0 && pending && !(R3M_PROBE(p) & (1 | 4 | 16))) {
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -480,7 +495,7 @@ static int pw_cu_count() {
 bool pw_gemm_eligible(const GatherGemmParams& p) {
   if (p.dtype != DT_F32 || p.ntaps != 1 || !p.simple_rows || p.os != 1 || p.T != 1) return false;
   if (p.dy[0] != 0 || p.dx[0] != 0 || p.wt[0] != 0) return false;
-  if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 127)) return false;
+  if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 63)) return false;       // widths: multiples of 128 (four-wave tile) or of 64 (eight-wave tile)
   switch (p.flags) {
     case 0: case EPI_STATS: case EPI_ACCUM: case EPI_BNRED: break;
     case EPI_MASKED_ADD: case EPI_BNRED | EPI_MASKED_ADD:
@@ -491,19 +506,21 @@ bool pw_gemm_eligible(const GatherGemmParams& p) {
   return true;
 }
 
-int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
-  constexpr int BM = 128, BN = 128;
+template <int BM, int BN, int WM, int WN>
+static int launch_pw_shape(const GatherGemmParams& p, hipStream_t s) {
+  constexpr int NW = WM * WN, TN = BN / WN / 32;
   const int gridM = ceil_div(p.M, BM), gridN = p.Nc / BN;
   const long long tiles_ll = (long long)gridM * gridN;
   R3M_REQUIRE(tiles_ll < 0x7FFFFFFFLL, "pw_gemm: too many tiles");
   const int tiles = (int)tiles_ll;
-  const int W = tiles < 2 * pw_cu_count() ? tiles : 2 * pw_cu_count();
-  constexpr int LDS = (2 * (BM + BN) * 32 + 2 * 2 * BN + 4 * 8 * 64) * 4;   // ring + statistics scratch + four 2 KB store slabs
-#define LAUNCH_PW(E, YB)                                                                                                          \
-  do {                                                                                                                           \
-    static DynLdsOptIn oi;                                                                                                       \
-    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, 2, 2, E, YB>), LDS, "pw_gemm")) return e; \
-    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, 2, 2, E, YB>), dim3(W), dim3(256), LDS, s, p, tiles, gridN);                       \
+  const int slots = (NW == 4 ? 2 : 1) * pw_cu_count();               // resident blocks: two four-wave blocks or one eight-wave block per CU
+  const int W = tiles < slots ? tiles : slots;
+  constexpr int LDS = (2 * (BM + BN) * 32 + WM * 2 * BN + NW * 8 * TN * 32) * 4;   // ring + statistics scratch + one 8-row store slab per wave
+#define LAUNCH_PW(E, YB)                                                                                                            \
+  do {                                                                                                                             \
+    static DynLdsOptIn oi;                                                                                                         \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB>), LDS, "pw_gemm")) return e; \
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);                   \
   } while (0)
   const bool yb = p.bn_bits != nullptr;
   switch (p.flags) {
@@ -521,6 +538,10 @@ int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   }
 #undef LAUNCH_PW
   return 0;
+}
+
+int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
+  return (p.Nc & 127) == 0 ? launch_pw_shape<128, 128, 2, 2>(p, s) : launch_pw_shape<256, 64, 4, 2>(p, s);
 }
 
 }  // namespace r3m

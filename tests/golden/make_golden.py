@@ -302,14 +302,18 @@ def step_golden(size=18, B=2, nsteps=2):
     perms = [torch.stack([torch.randperm(B) for _ in range(6)]) for _ in range(nsteps)]
     torch.manual_seed(seed)
     T = trainer.Trainer(1)
+    lb = last_bn_name(size)
+    last_conv = lb.replace("bn", "conv")
     for s in range(nsteps):
         metrics, _ = T.update(model, (frames, [""] * B), s)
         out[f"metric_values_{s}"] = np.array(list(metrics.values()), dtype=np.float64)
         out["metric_names"] = np.array(list(metrics.keys()))
         out[f"perms_{s}"] = perms[s].numpy()
+        if s == 0:     # weights after the FIRST Adam step (every weight moved by ~lr with the sign of its gradient)
+            sd1 = m.convnet.state_dict()
+            for k in ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight"):
+                out["post1_" + k] = sd1[k].numpy().copy()
     sd = m.convnet.state_dict()
-    lb = last_bn_name(size)
-    last_conv = lb.replace("bn", "conv")
     for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", lb + ".weight",
               last_conv + ".weight", "layer1.0.conv1.weight"):
         out["post_" + k] = sd[k].numpy().copy() if sd[k].numel() < 50000 else sd[k].numpy().reshape(-1)[:50000].copy()

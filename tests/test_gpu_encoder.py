@@ -219,8 +219,13 @@ def test_full_step_matches_reference_golden(hip, golden_dir, size):
     torch.manual_seed(77)
     T = Trainer(1)
     names = [str(n) for n in g["metric_names"]]
+    after1 = {}
     for s in range(2):
         metrics, _ = T.update(model, (frames, [""] * 2), s)
+        if s == 0:
+            torch.cuda.synchronize()
+            sd1 = m.convnet.state_dict()
+            after1 = {k: sd1[k].detach().cpu().numpy().copy() for k in ("conv1.weight", "bn1.weight", "bn1.bias", _last_bn(size) + ".weight")}
         assert list(metrics.keys()) == names
         ref = dict(zip(names, g[f"metric_values_{s}"]))
         # step 0 sees identical weights: tight. Step 1 follows an Adam update whose first step moves every weight by
@@ -234,13 +239,29 @@ def test_full_step_matches_reference_golden(hip, golden_dir, size):
             assert abs(metrics[k] - ref[k]) <= tol * max(1.0, abs(ref[k])), (s, k, metrics[k], ref[k])
     sd = m.convnet.state_dict()
     lr = 1e-4
+    # After the FIRST Adam step every weight has moved by ~lr with the SIGN of its gradient: against the reference's weights only
+    # the elements whose gradient is round-off in sign differ (by 2 lr). Gate: <= 2.1 lr and fewer than 15 % of the elements
+    # beyond 0.2 lr (captured in `after1` below, inside the loop). After the SECOND step the updates come from gradients at weights
+    # that already differ, and ResNet-50's conv1 / bn1 gradients sit 2e-2 from float64 in ANY fp32 evaluation (kink-free case
+    # below) — measured 40 % of its bn1 elements beyond 0.2 lr against 5-11 % for ResNet-18 / 34 — so there only the bound of two
+    # steps (<= 4.2 lr) is gated and the fraction is reported.
+    fails = []
+    for k, got1 in after1.items():
+        ref1 = g["post1_" + k].reshape(-1)
+        d = np.abs(got1.reshape(-1) - ref1)
+        flipped = float((d > 0.2 * lr).mean())
+        report(f"r{size} after step 1 {k}: max abs diff {d.max() / lr:.2f} lr, fraction beyond 0.2 lr {flipped:.3f}")
+        if not (d.max() <= 2.1 * lr and flipped < 0.15):
+            fails.append(("step1", k, float(d.max()), flipped))
     for k in ("bn1.weight", "bn1.bias", _last_bn(size) + ".weight", "conv1.weight"):
         got = sd[k].cpu().numpy().reshape(-1)[:50000]
         ref = g["post_" + k].reshape(-1)
         d = np.abs(got - ref)
         flipped = float((d > 0.2 * lr).mean())
-        print("post-step", k, "max abs diff", d.max(), "fraction beyond 0.2*lr", flipped)
-        assert d.max() <= 4 * lr * 1.05 and flipped < 0.15, k     # two steps of at most 2*lr each, for few elements
+        report(f"r{size} after step 2 {k}: max abs diff {d.max() / lr:.2f} lr, fraction beyond 0.2 lr {flipped:.3f}")
+        if not d.max() <= 4 * lr * 1.05 or (size != 50 and not flipped < 0.15):
+            fails.append(("step2", k, float(d.max()), flipped))
+    assert not fails, fails
     # running statistics after TWO steps: 0.9 x (step-1 statistics, gated at 1e-4 by the encoder golden) + 0.1 x the statistics of
     # conv1 outputs under weights that already took one Adam step — and that step moves a weight by +-lr according to the SIGN of
     # its gradient (see above), so a few conv1 weights differ by 2 lr = 2e-4 from the reference's: 1e-4-level differences in the
