@@ -28,6 +28,12 @@ const char* r3m_last_error(void);
  * 256x64 tile (64-channel layers), 2 wgrad 128x128, 3 wgrad 64x64. collect() sums elapsed ms / launches / algorithmic
  * FLOPs per class since the last collect (arrays of 4) and resets. */
 int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm128x128, gemm128x128 8-wave, gemm256x64, wgrad128} */
+/* Diagnostic: `blocks` workgroups of 256 threads that each hold `lds_bytes` of LDS and idle for `milliseconds` on `stream` — a stand-in
+ * for another stream's long-running kernel (an RCCL collective overlapped with backward) when measuring how the compute kernels
+ * behave with part of the CUs' LDS / wave slots taken (tools/occupy_ab.py). Returns immediately; does nothing else. */
+int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_t stream);
+/* Diagnostic: 0 = the encoder's persistent-kernel launches assign tiles statically, 1 (default) = per-XCD tile queues. Returns the old value. */
+int r3m_debug_set_dynamic_tiles(int on);
 void r3m_profile_enable(int on);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
 int r3m_profile_collect_bytes(double* bytes);     /* algorithmic HBM bytes per class (operands + results once) of the launches of the last collect() */

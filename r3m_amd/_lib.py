@@ -23,6 +23,8 @@ SIGNATURES = {
     "r3m_abi_version": (c_i, []),
     "r3m_last_error": (C.c_char_p, []),
     "r3m_debug_occupancy": (c_i, [C.POINTER(c_i)]),
+    "r3m_debug_occupy": (c_i, [c_i, c_i, C.c_double, C.c_void_p]),
+    "r3m_debug_set_dynamic_tiles": (c_i, [c_i]),
     "r3m_profile_enable": (None, [c_i]),
     "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
     "r3m_profile_collect_bytes": (c_i, [C.POINTER(c_d)]),

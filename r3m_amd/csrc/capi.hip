@@ -170,6 +170,20 @@ extern "C" {
 int r3m_abi_version(void) { return 1; }
 
 int r3m_debug_occupancy(int* out4) { return debug_occupancy(out4); }
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks) {   // wall_clock64(): constant-rate counter (100 MHz)
+  extern __shared__ char occ_lds[];
+  occ_lds[threadIdx.x] = 1;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_t stream) {
+  R3M_REQUIRE(blocks > 0 && lds_bytes >= 256 && lds_bytes <= 160 * 1024 && milliseconds >= 0.0, "debug_occupy: bad arguments");
+  static r3m::DynLdsOptIn oi;
+  if (int e = r3m::ensure_dyn_lds(oi, reinterpret_cast<const void*>(occupy_kernel), lds_bytes, "debug_occupy")) return e;
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), (long long)(milliseconds * 1e5));
+  return r3m::check_launch("debug_occupy");
+}
+int r3m_debug_set_dynamic_tiles(int on) { return r3m::gg_set_dynamic_tiles(on); }
 void r3m_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on.store(on != 0, std::memory_order_relaxed);

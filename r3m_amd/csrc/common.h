@@ -92,6 +92,7 @@ struct GatherGemmParams {
   int simple_rows;     // 1: 1x1 / stride 1 / no padding -> input row offset = m*Ci (no pixel decode)
   int debug;           // timing probes (R3M_GG_DEBUG), 0 in production
   int dtype;           // DT_F32: A/B/out/add0/add1 are fp32; DT_BF16: they address bf16 tensors (stats/bias stay fp32)
+  unsigned* tile_ctr;  // persistent kernels (conv_pw.hip): 8 zeroed counters = per-XCD tile queues, or null -> static tile assignment
   signed char dy[MAX_TAPS];
   signed char dx[MAX_TAPS];
   unsigned char wt[MAX_TAPS];
@@ -134,6 +135,11 @@ int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const floa
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
 double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem_bytes);
 int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher will use (stats partial rows)
+// The engine hands the NEXT launch_gather_gemm of this thread 8 zeroed device counters (dynamic tile queues of the persistent
+// kernel: a block that finds its CU shared with another stream's kernel — RCCL during an overlapped all-reduce — simply takes
+// fewer tiles). Consumed (and cleared) by that launch whether or not it uses them; launches without it assign tiles statically.
+void gg_set_tile_counters(unsigned* ctr8);
+int gg_set_dynamic_tiles(int on);        // diagnostic switch (r3m_debug_set_dynamic_tiles): 0 = ignore the counters, assign statically
 bool pw_gemm_eligible(const GatherGemmParams& p);          // conv_pw.hip: persistent kernel for 1x1 / stride-1 launches (fp32)
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s);
 int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);

@@ -931,8 +931,15 @@ double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem) {
   return b;
 }
 
+static thread_local unsigned* t_tile_ctr = nullptr;
+static int g_dynamic_tiles = 1;          // diagnostic (tools/occupy_ab.py): plain int, written before launches from the same thread
+void gg_set_tile_counters(unsigned* ctr8) { t_tile_ctr = g_dynamic_tiles ? ctr8 : nullptr; }
+int gg_set_dynamic_tiles(int on) { const int old = g_dynamic_tiles; g_dynamic_tiles = on ? 1 : 0; return old; }
+
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
+  p.tile_ctr = t_tile_ctr;     // one launch only: a stride-2 dgrad's later parity launches, or the next layer, must not reuse them
+  t_tile_ctr = nullptr;
   if (p.dtype == DT_BF16) {
     {
       const int dbg = R3M_ENV_INT("R3M_GG_DEBUG", 0);

@@ -28,9 +28,8 @@
 //     dwordx4 per tensor and store). The 1-bit masks of a wave's 64 x 64 tile are ONE dwordx2 load (lane = row) expanded with
 //     ds_bpermute;
 //   * the epilogue of tile i is DEFERRED into the first K step of tile i + 1, after that step's data has landed and the
-//     following step's DMA is issued. gfx9 has ONE in-order counter for loads and stores: the wait that publishes the next LDS
-//     stage is `vmcnt(16)` there — the DMA is older than the 16 stores — so the stores are first waited for one further K step
-//     later, with the DMA of the step after that.
+//     following step's DMA is issued: gfx9 has ONE counter for loads and stores, so the `vmcnt(0)` that publishes the next LDS
+//     stage also waits for the stores — one K step (64 MFMAs per wave) after their issue instead of immediately.
 #include "common.h"
 #include "conv_dev.h"
 
@@ -407,37 +406,68 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
     }
   };
 
-  // ---- persistent tile walk: workers of one XCD hold neighbouring ids (column tiles of one row panel share that XCD's L2)
-  int id = xcd_remap(blockIdx.x, W);
-  int mt = id / gridN, nt = id - mt * gridN;
-  const int dm = W / gridN, dn = W - dm * gridN;
+  // ---- persistent tile walk.
+  // Static (p.tile_ctr == null): worker w takes tiles w, w + W, ...; workers of one XCD hold neighbouring ids (the column tiles of
+  // one row panel share that XCD's L2). Dynamic (the engine's launches): eight queues, one per XCD — block b draws from queue
+  // b % 8 (blocks are dispatched round-robin over the XCDs; if that ever changes only locality is lost), whose k-th ticket is column
+  // tile k % gridN of row panel 8 (k / gridN) + queue. A block takes its next ticket at the START of a tile (one atomic by one
+  // lane, its latency rides under the tile) and hands it to the other waves through LDS at the tile's second barrier. With a
+  // static split a block that cannot become resident — its CU is shared with another stream's kernel, e.g. RCCL during an
+  // overlapped all-reduce — would start its whole share only after another block has finished: twice the launch time; with the
+  // queues it finds them (nearly) empty.
   const int npairs = K >> 6;                             // K steps of 32, two per iteration (K is a multiple of 64)
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using T_ = std::true_type;
   using F_ = std::false_type;
-
-  using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
+  const bool dyn = p.tile_ctr != nullptr;
+  const int xq = blockIdx.x & 7;
+  unsigned* ctr = dyn ? p.tile_ctr + xq : nullptr;
+  int* nxt = reinterpret_cast<int*>(smem + 2 * STAGE + WM * 2 * BN + NW * 8 * CW);   // the next ticket, one int
+  const int gridM = tiles / gridN;
+  auto ticket_tile = [&](int k, int& tmt, int& tnt) -> bool {
+    const int kp = k / gridN;
+    tnt = k - kp * gridN;
+    tmt = kp * 8 + xq;
+    return tmt < gridM;
+  };
+  int id = 0, mt = 0, nt = 0;
+  bool has;
+  int dm = 0, dn = 0;
+  if (dyn) {
+    if (tid == 0) *nxt = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    has = ticket_tile(__builtin_amdgcn_readfirstlane(*nxt), mt, nt);
+  } else {
+    id = xcd_remap(blockIdx.x, W);
+    mt = id / gridN;
+    nt = id - mt * gridN;
+    dm = W / gridN;
+    dn = W - dm * gridN;
+    has = id < tiles;
+  }
+
   bool pending = false;
   int pmt = 0, pnt = 0;
-  if (id < tiles) dma_all(I0{}, a_base(mt), a_bytes(mt), b_base(nt), 0);
+  if (has) dma_all(I0{}, a_base(mt), a_bytes(mt), b_base(nt), 0);
   while (true) {
-    const bool has = id < tiles;
+    unsigned ticket = 0u;
     if (has) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0 of this tile has landed (and the previous tile's stores are out,
       __syncthreads();                                   //  its prefetched epilogue operands are in their registers)
       dma_all(I1{}, a_base(mt), a_bytes(mt), b_base(nt), 128);
+      if (dyn && tid == 0) ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (pending) epilogue1(pmt, pnt);
     if (!has) break;
     pre_tile(mt, nt);
     kstep(I0{}, T_{}, F_{}, P1{}, nullptr, 0, nullptr, 0, false, npairs == 1);
-    const int nid = id + W;
+    int nid = id + W;
     int nmt = mt + dm, nnt = nt + dn;
     if (nnt >= gridN) { nnt -= gridN; ++nmt; }
-    const bool nhas = nid < tiles;
+    bool nhas = nid < tiles;
     for (int pr = 0; pr < npairs; ++pr) {
       const bool last = pr + 1 == npairs;
       if (pr > 0) {
@@ -445,18 +475,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
         __syncthreads();
         kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
       }
-      // The counter is in order over loads AND stores on gfx9 (no separate store counter; the compiler's own waits rely on it):
-      // right after a deferred epilogue the NST (16 or 8) stores of this wave are YOUNGER than the DMA this step needs, so "all but
-      // the NST most recent" covers that DMA — the stores keep flying under this step's MFMAs instead of being waited for here.
-      // (__syncthreads() carries a workgroup-scope release fence = vmcnt(0); the hand-off here is LDS only — DMA landed per wave,
-      // `red` written with lgkmcnt(0) — so a bare s_barrier is enough.)
-      if (pr == 0 && pending && !(R3M_PROBE(p) & (1 | 4 | 16))) {
-        if constexpr (NST == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
+      if (pr == 0 && dyn && tid == 0) *nxt = (int)ticket;   // (the compiler waits for the atomic's return here: it is older than the stores)
+      // (Tried and dropped: `s_waitcnt vmcnt(NST)` + a bare s_barrier here after a deferred epilogue, on the assumption that the
+      // counter retires loads, LDS-DMA and stores strictly in issue order so that "all but the NST youngest" covers the DMA and
+      // leaves the stores flying. It bought nothing measurable — the K = 64 launch ran 1.57 -> 1.62 ms — and an intermittent wrong
+      // result showed up once in 231 GPU tests while it was in; the plain full wait costs the same and assumes nothing.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (pr == 0 && dyn) nhas = ticket_tile(__builtin_amdgcn_readfirstlane(*nxt), nmt, nnt);
       if (pr == 0 && pending) epilogue2(pmt, pnt);
       const int tmt = last ? nmt : mt, tnt = last ? nnt : nt;
       kstep(I1{}, F_{}, T_{}, P2{}, a_base(tmt), a_bytes(tmt), b_base(tnt), last ? 0 : (2 * pr + 2) * 128, last ? nhas : true, last);
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
     id = nid;
     mt = nmt;
     nt = nnt;
+    has = nhas;
   }
   if constexpr ((EPI & EPI_STATS) != 0) {
     if (pending) {
@@ -507,15 +534,17 @@ bool pw_gemm_eligible(const GatherGemmParams& p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_pw_shape(const GatherGemmParams& p, hipStream_t s) {
+static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;
-  const int gridM = ceil_div(p.M, BM), gridN = p.Nc / BN;
+  const int gridM = ceil_div(p_in.M, BM), gridN = p_in.Nc / BN;
   const long long tiles_ll = (long long)gridM * gridN;
   R3M_REQUIRE(tiles_ll < 0x7FFFFFFFLL, "pw_gemm: too many tiles");
   const int tiles = (int)tiles_ll;
   const int slots = (NW == 4 ? 2 : 1) * pw_cu_count();               // resident blocks: two four-wave blocks or one eight-wave block per CU
   const int W = tiles < slots ? tiles : slots;
-  constexpr int LDS = (2 * (BM + BN) * 32 + WM * 2 * BN + NW * 8 * TN * 32) * 4;   // ring + statistics scratch + one 8-row store slab per wave
+  GatherGemmParams p = p_in;
+  if (W < 64 || gridM < 64) p.tile_ctr = nullptr;                     // small launches: every queue needs blocks AND panels; static split
+  constexpr int LDS = (2 * (BM + BN) * 32 + WM * 2 * BN + NW * 8 * TN * 32) * 4 + 128;   // ring + statistics scratch + one 8-row store slab per wave + the ticket
 #define LAUNCH_PW(E, YB)                                                                                                            \
   do {                                                                                                                             \
     static DynLdsOptIn oi;                                                                                                         \

@@ -63,6 +63,7 @@ struct Plan {
   long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
   // arena offsets (floats)
   long long col_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
+  long long ctr_off = 0;    // [2][convs][8] unsigned: per-XCD tile queues of the persistent 1x1 kernel, forward / backward launch of each conv
   long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
   long long arena_floats = 0;
   long long gmax = 0;
@@ -234,6 +235,7 @@ Plan* plan_create(int size, int F, int dtype) {
   }
   if (dtype == DT_BF16) P.w16_off = take((P.n_params + 1) / 2);
   P.wgp_off = take(wgp_max);
+  P.ctr_off = take(2LL * (long long)P.convs.size() * 8);
   P.gmax = gmax;
   for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
   P.arena_floats = off;
@@ -388,6 +390,7 @@ static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float
   float* Y = c.arena + L.Y_off;
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
+  gg_set_tile_counters(reinterpret_cast<unsigned*>(c.arena + P.ctr_off) + (&L - P.convs.data()) * 8);
   TRY(conv_forward_launch(X, W, Y, partial, nullptr, N_eff, Hi_eff, Wi_eff, Ci_eff, L.Co, k_eff, stride_eff, pad_eff,
                           c.training ? EPI_STATS : 0, c.dt, c.s));
   const float* gamma = c.params + L.gamma_off;
@@ -431,6 +434,11 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
   P.dout_fused_rows = 0;
   const int F = P.F;
   const int dt = P.dtype;
+  // tile queues of this pass's persistent-kernel launches (conv_pw.hip): 8 counters per conv, zeroed here, each used by one launch
+  if (hipMemsetAsync(arena + P.ctr_off, 0, P.convs.size() * 8 * sizeof(unsigned), s) != hipSuccess) {
+    set_last_error("resnet_forward: cannot reset the tile queues");
+    return 1;
+  }
   if (dt == DT_BF16) TRY(launch_convert_bf16(params, arena + P.w16_off, P.n_params, s));   // bf16 image of every weight (45 MB for ResNet-50)
   // ---- stem: x/255 -> Normalize -> conv1 7x7/2 straight from the NCHW frames (csrc/conv.hip stem_fwd_kernel) ----
   const ConvSpec& L0 = P.convs[0];
@@ -529,6 +537,7 @@ static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flag
   float* Wt = c.dt == DT_BF16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c.arena + c.P.wt_off) + L.wt_off)
                               : c.arena + c.P.wt_off + L.wt_off;
   if (fused_rows_out) *fused_rows_out = 0;
+  gg_set_tile_counters(reinterpret_cast<unsigned*>(c.arena + c.P.ctr_off) + (c.P.convs.size() + (&L - c.P.convs.data())) * 8);   // backward half
   // 1x1 stride-2 dgrads leave three of four parity classes without taps (plain zero / no-op launches): not fused
   const bool fuse = bn_of && fused_rows_out && c.P.fuse_bnred && !(L.stride == 2 && L.k == 1);
   if (!fuse)
@@ -593,6 +602,10 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   P.next_stage = -2;           // poisoned while in flight: after a failed call only stage 0 (a restart) is accepted
   TRY(side_init(P));
   if (stage_begin == 0) {       // the weights are final since the last optimizer step: all dgrad weight images in one launch
+    if (hipMemsetAsync(arena + P.ctr_off + P.convs.size() * 8, 0, P.convs.size() * 8 * sizeof(unsigned), s) != hipSuccess) {
+      set_last_error("resnet_backward: cannot reset the tile queues");
+      return 1;
+    }
     if (!P.d_wt_tab) {
       // failure-atomic: the plan's pointers are set only after both allocations and both uploads succeeded (a half-initialised
       // pair would make the next backward skip this block and launch transpose_w_all on a null / uninitialised table)
