@@ -28,7 +28,7 @@ MB_PER_FRAME_BF16 = {50: 289.8, 34: 97.1, 18: 64.5}          # algorithmic HBM b
 PEAK_HBM_GBS = 8000.0                                        # HBM3E spec (≈6300 GB/s achievable), MI355X_MICROARCH.md
 PEAK_FP32_MFMA_TFLOPS = 157.3                                # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0                               # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), not the 2:1-sparse figure
-KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad; 32- and 16-wide-K kernels, all epilogues incl. the BatchNorm-backward partials)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
+KCLASS = ["gather_gemm_128x128 (conv fwd/dgrad: gather, 3x3-window, 16-wide-K and persistent 1x1 kernels, all epilogues incl. the BatchNorm-backward partials)", "gather_gemm_256x64 (64-channel conv fwd/dgrad)", "wgrad_128x128",
           "wgrad_64x64"]
 
 
@@ -453,7 +453,8 @@ def main():
         else:
             dist.init_process_group("gloo")
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "binding": None}
-    if use_dist and world > 1 and not args.no_bind and not args.share_gpu:
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if use_dist and not args.no_bind and not args.share_gpu:      # also a one-rank group under a launcher: same code as N = 8
         # one rank per GPU on a two-socket host: the launching thread (≈1000 launches per step) stays on cores of its GPU's NUMA
         # node, ranks get disjoint cores, torch's intra-op pool is capped (round 3: foreign threads next to the launcher cost up
         # to +85 ms on a 94 ms step)
@@ -488,6 +489,8 @@ def main():
             out["secondary"] = sec
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            if affinity0 is not None:
+                os.sched_setaffinity(0, affinity0)       # the CPU baseline uses the host's cores, not the rank's NUMA slice
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_clips)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -459,6 +459,12 @@ def test_bench_spawns_its_own_ranks(hip):
     out = _run_bench(["--gpus", str(n)] + (["--force-launcher"] if n == 1 else []))
     assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["value"] > 0
     assert out["config"]["collectives"].startswith(f"rccl all_reduce(AVG), {ENC_SLICES[18]:.1f} per step")
+    # per-rank lines and the host placement every rank reports (NUMA node of its GPU from sysfs, its own cores, capped torch threads)
+    assert len(out["ms_per_step_by_rank"]) == n and len(out["comm_exposed_ms_by_rank"]) == n
+    assert max(out["ms_per_step_by_rank"]) == out["ms_per_step"]
+    hb = out["host_binding"]
+    assert len(hb) == n and all(b["local_rank"] == i for i, b in enumerate(hb))
+    assert all(("error" in b) or (b["cpus"] and b["threads"] >= 1) for b in hb), hb
     assert out["config"]["frames_per_gpu"] == 40 and out["scaling"] == "weak"
     assert out["ms_per_step_rank_min"] <= out["ms_per_step"] == out["ms_per_step_rank_max"]
     assert out["comm_exposed_ms"] >= 0.0

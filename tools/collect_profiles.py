@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Copy the summaries of the last tools/gpu_evidence.sh run from gpurun_out/ (scratch) into profiles/ (tracked) under one tag:
-usage: collect_profiles.py r02_v1"""
+usage: collect_profiles.py r04_v1"""
 import os
 import shutil
 import subprocess
@@ -18,9 +18,10 @@ for f in os.listdir(G):
 for src, dst in copy.items():
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, f"{tag}_{dst}"))
-for prec, sfx, js in (("fp32", "", "pmc_latest.json"), ("bf16", "_bf16", "pmc_latest_bf16.json")):
+for prec, sfx, js, size, clips in (("fp32", "", "pmc_latest.json", 50, 256), ("bf16", "_bf16", "pmc_latest_bf16.json", 50, 256),
+                                   ("bf16_r34", "_bf16_r34", "pmc_latest_bf16_r34.json", 34, 512)):
     if os.path.exists(os.path.join(G, f"pmc_pass1{sfx}.csv")):
-        subprocess.check_call([sys.executable, "tools/pmc_report.py", G, os.path.join(P, f"{tag}_pmc_{prec}"), sfx, js])
+        subprocess.check_call([sys.executable, "tools/pmc_report.py", G, os.path.join(P, f"{tag}_pmc_{prec}"), sfx, js, str(size), str(clips)])
 for prec in ("fp32", "bf16"):
     csvf = os.path.join(G, f"launches_{prec}.csv")
     if os.path.exists(csvf):

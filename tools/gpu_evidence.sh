@@ -33,6 +33,7 @@ for t in "fp32:" "bf16:--precision bf16" "r34c4:--size 34 --clips-per-gpu 512 --
 done
 bash tools/gpu_pmc.sh 256 fp32 "" > gpurun_out/pmc_fp32.log 2>&1
 bash tools/gpu_pmc.sh 256 bf16 _bf16 > gpurun_out/pmc_bf16.log 2>&1
+bash tools/gpu_pmc.sh 512 bf16 _bf16_r34 "--size 34 --doaug rctraj" > gpurun_out/pmc_bf16_r34.log 2>&1
 python - <<'PY'
 import glob, json
 for f in sorted(glob.glob('gpurun_out/bench_*.json') + glob.glob('gpurun_out/cfg_*.json')):
