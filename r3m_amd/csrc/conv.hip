@@ -988,7 +988,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
         return check_launch("conv3x3_win");
       }
     }
-    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // 1x1 / stride 1: persistent kernel (conv_pw.hip)
+    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // dense output rows (1x1 / stride 1; any forward; stride-1 dgrads): persistent kernel (conv_pw.hip)
       if (int e = launch_pw_gemm(p, s)) return e;
       prof_bytes(gather_gemm_alg_bytes(p, 4));
       prof_end(s);
@@ -1018,7 +1018,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // 1x1 / stride 1, 64-wide output: persistent kernel, eight-wave 256 x 64 tile
+    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // dense output rows, 64-wide output: persistent kernel, eight-wave 256 x 64 tile
       if (int e = launch_pw_gemm(p, s)) return e;
       prof_bytes(gather_gemm_alg_bytes(p, 4));
       prof_end(s);

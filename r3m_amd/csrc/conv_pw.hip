@@ -61,10 +61,23 @@ __device__ __forceinline__ f32x4 pw_ld4(const void* base, int bytes, unsigned vo
   return f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
 }
+// HAZARD (found the hard way, round 4): a VMEM store of more than 64 bits reads its data registers over several cycles; a vector
+// instruction that overwrites them in the very next slot corrupts what some lanes store. The compiler's hazard recognizer inserts
+// the wait states only when the store's soffset operand is NOT a register ("this hazard only exists if the instruction is not
+// using a register in the soffset field") — on gfx950 it exists with a scalar soffset too: `buffer_store_dwordx4 v[42:45] ... s20
+// offen` followed immediately by `v_cndmask_b32 v45, 0, v45` (EPI_BNRED masks the stored value in place) stored a zero in element
+// 3 of lanes 12-15 of each 16-lane group — sporadically, only in blocks that share their CU with an earlier block, and only after
+// other kernels had run in the process (tests/test_gpu_ops.py, the `bits` cases with more tiles than workers). A separate
+// `s_nop` statement after the builtin does not help: the scheduler slides vector instructions between the two. So the store and
+// its wait states are ONE inline-asm statement.
+#ifndef PW_ST_MOD
+#define PW_ST_MOD ""   // cache policy of the result stores (experiment switch: " nt", " sc1", " sc0 sc1")
+#endif
 __device__ __forceinline__ void pw_st4(void* base, int bytes, unsigned voff, int soff, f32x4 v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pw_u32x4, v), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, PW_RSRC_FLAGS), voff,
-                                         soff, 0);
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const pw_u32x4 rsrc = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, (unsigned)bytes, (unsigned)PW_RSRC_FLAGS};   // stride 0: raw buffer
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" PW_ST_MOD "\n\ts_nop 3" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
 }
 typedef unsigned pw_u32x2 __attribute__((ext_vector_type(2)));
@@ -82,12 +95,22 @@ __device__ __forceinline__ void pw_st(void* base, int bytes, unsigned voff, int 
 #endif
 }
 
+__device__ __forceinline__ const float* pw_uniform_ptr(const float* q) {   // a wave-uniform pointer, in scalar registers
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 // EPI: 0, EPI_STATS, EPI_ACCUM, EPI_MASKED_ADD (1-bit mask only), EPI_BNRED, EPI_BNRED | EPI_MASKED_ADD
 // YBITS (EPI_BNRED): the consumer BatchNorm's ReLU mask comes as bits (block outputs) / is recomputed from y (inner BatchNorms)
 // Two shapes: <128, 128, 2, 2> — four waves of 64 x 64, two blocks per CU — for outputs whose width is a multiple of 128, and
 // <256, 64, 4, 2> — EIGHT waves of 64 x 32 (TN = 1), one block per CU — for the 64-channel outputs (conv1 / the dgrad of conv3 in
 // layer1): the 256-row tile keeps the statistics partial-row geometry of the other 64-wide kernels (gather_gemm_grid_m).
-template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false>
+// GATHER: the A rows are pixels of an NHWC tensor selected per tap ((gy is + dy, gx is + dx), zero outside the image) instead of
+// rows of a matrix: every convolution whose OUTPUT rows are dense (forward of any k / stride / pad, dgrad of stride-1 layers). The
+// row -> pixel decode runs once per tile, a tap switch is ~7 vector instructions per staged row (offset + bounds test -> out-of-range
+// offset), everything else is the pointwise kernel.
+template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false, bool GATHER = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;        // waves; 32-column MFMA tiles per wave (2 or 1)
   static_assert(BM / WM == 64 && (TN == 1 || TN == 2) && (NW == 4 || NW == 8), "wave tile is 64 rows x 32 TN columns");
@@ -108,33 +131,104 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   // ---- DMA: wave w stages rows [w BM/NW, +BM/NW) of A and [w BN/NW, +BN/NW) of B, 8 rows (1 KiB) per instruction; the 16-byte
   // slot a lane fetches is XOR-swizzled by (row >> 1) & 7 (conv.hip, glds2 kernel). Offsets are constants of the kernel.
   unsigned voffA[AJ], voffB[BJ];
+  const int KbB = (GATHER ? p.T : 1) * Kb;              // bytes of one weight row: [tap][Ci]
   {
     const int srow = lane >> 3, pslot = lane & 7;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int r = wave_s * (BM / NW) + j * 8 + srow;
-      voffA[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
+      voffA[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));          // GATHER: recomputed per tile and tap (set_tap)
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int r = wave_s * (BN / NW) + j * 8 + srow;
-      voffB[j] = (unsigned)(r * Kb + ((pslot ^ ((r >> 1) & 7)) << 4));
+      voffB[j] = (unsigned)(r * KbB + ((pslot ^ ((r >> 1) & 7)) << 4));
     }
   }
-  auto dma_piece = [&](auto stg_c, auto pc_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
+  // the source the NEXT DMA pieces read from (scalars): A / B descriptor of the tile being staged, K position of the step
+  const float* dA = p.A;
+  const float* dB = p.B;
+  int dAbytes = 0, dsA = 0, dsB = 0;
+  auto dma_piece = [&](auto stg_c, auto pc_c) __attribute__((always_inline)) {
     constexpr int STG = decltype(stg_c)::value, pc = decltype(pc_c)::value;
     if (R3M_PROBE(p) & 8) return;                         // timing probe: no DMA (stale LDS)
+    // (the descriptors are loop-carried scalars; pinned to scalar registers or the compiler may park them in vector registers and
+    // wrap each DMA instruction in a waterfall loop — conv_dev.h, buf_dma16_uniform)
     if constexpr (pc < AJ)
-      buf_dma16(ab, abytes, smem + STG * STAGE + wave_s * (BM / NW) * 32 + pc * 8 * 32, voffA[pc], soff);
+      buf_dma16_uniform(dA, dAbytes, smem + STG * STAGE + wave_s * (BM / NW) * 32 + pc * 8 * 32, voffA[pc], dsA);
     else
-      buf_dma16(bb, BN * Kb, smem + STG * STAGE + BM * 32 + wave_s * (BN / NW) * 32 + (pc - AJ) * 8 * 32, voffB[pc - AJ], soff);
+      buf_dma16_uniform(dB, BN * KbB, smem + STG * STAGE + BM * 32 + wave_s * (BN / NW) * 32 + (pc - AJ) * 8 * 32, voffB[pc - AJ], dsB);
   };
-  auto dma_all = [&](auto stg_c, const float* ab, int abytes, const float* bb, int soff) __attribute__((always_inline)) {
-    static_for<NP>([&](auto pc_c) __attribute__((always_inline)) { dma_piece(stg_c, pc_c, ab, abytes, bb, soff); });
+  auto dma_all = [&](auto stg_c) __attribute__((always_inline)) {
+    static_for<NP>([&](auto pc_c) __attribute__((always_inline)) { dma_piece(stg_c, pc_c); });
   };
-  auto a_base = [&](int mt) -> const float* { return p.A + (long long)mt * BM * K; };
-  auto a_bytes = [&](int mt) -> int { return min(BM, p.M - mt * BM) * Kb; };
-  auto b_base = [&](int nt) -> const float* { return p.B + (long long)nt * BN * K; };
+  // GATHER row state of the tile being staged: byte offset of the row's top-left input pixel from the tile's first frame (+ the
+  // lane's swizzled slot), and (iy0 << 16 | ix0) for the bounds test; rows past M sit far outside every image
+  unsigned poff[GATHER ? AJ : 1], iyx[GATHER ? AJ : 1];
+  int tap_soffB = 0;
+  auto aim_tile = [&](int tmt_, int tnt_) __attribute__((always_inline)) {     // descriptors (+ GATHER: row decode) of tile (tmt, tnt)
+    // tile coordinates are wave-uniform; say so, or the descriptors end up in vector registers and every DMA instruction in a
+    // waterfall loop (the uniform integer division below is expanded on the vector unit)
+    const int tmt = __builtin_amdgcn_readfirstlane(tmt_), tnt = __builtin_amdgcn_readfirstlane(tnt_);
+    dB = p.B + (long long)tnt * BN * (KbB / 4);
+    if constexpr (!GATHER) {
+      dA = p.A + (long long)tmt * BM * K;
+      dAbytes = min(BM, p.M - tmt * BM) * Kb;
+    } else {
+      const int hw = p.Hg * p.Wg;
+      const int m0t = tmt * BM;
+      const int nf = __builtin_amdgcn_readfirstlane(m0t / hw);   // first frame of the tile (uniform): 32-bit offsets are relative to it
+      const long long frame = (long long)p.Hi * p.Wi * K;
+      dA = pw_uniform_ptr(p.A + nf * frame);
+      const long long rest = (long long)(p.N - nf) * frame * 4;
+      dAbytes = __builtin_amdgcn_readfirstlane(rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB);
+      const int srow = lane >> 3, pslot = lane & 7;
+      const int r0 = wave_s * (BM / NW) + srow;
+      int m = m0t + r0;
+      int n = m / hw;
+      int rem = m - n * hw;
+      int gy = rem / p.Wg;
+      int gx = rem - gy * p.Wg;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int r = r0 + j * 8;
+        const int iy0 = gy * p.is, ix0 = gx * p.is;
+        poff[j] = (unsigned)(((((n - nf) * p.Hi + iy0) * p.Wi + ix0) * K) * 4 + ((pslot ^ ((r >> 1) & 7)) << 4));
+        iyx[j] = m < p.M ? (unsigned)((iy0 << 16) | ix0) : 0x40004000u;
+        m += 8;                                           // the lane's next row is 8 GEMM rows further: branch-free carries
+        gx += 8;                                          // (Wg >= 4: at most two row wraps; Hg >= 2: at most two frame wraps — pw_gemm_form)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const bool c = gx >= p.Wg;
+          gx -= c ? p.Wg : 0;
+          gy += c ? 1 : 0;
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const bool c = gy >= p.Hg;
+          gy -= c ? p.Hg : 0;
+          n += c ? 1 : 0;
+        }
+      }
+    }
+  };
+  auto set_tap = [&](int t) __attribute__((always_inline)) {                   // GATHER: per-lane offsets of tap t of the aimed tile
+    if constexpr (GATHER) {
+      const int pack = __builtin_amdgcn_readfirstlane(p.tap[t]);
+      const int dy = (pack << 24) >> 24, dx = (pack << 16) >> 24, wt = pack >> 16;
+      const int delta = (dy * p.Wi + dx) * Kb;            // scalar
+      tap_soffB = wt * Kb;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const unsigned iy = (iyx[j] >> 16) + (unsigned)dy, ix = (iyx[j] & 0xFFFFu) + (unsigned)dx;
+        voffA[j] = (iy < (unsigned)p.Hi && ix < (unsigned)p.Wi) ? poff[j] + (unsigned)delta : BUF_OOB;
+      }
+    }
+  };
+  auto aim_step = [&](int chunk) __attribute__((always_inline)) {              // K position inside the current tap: 32-channel chunk
+    dsA = __builtin_amdgcn_readfirstlane(chunk * 128);
+    dsB = __builtin_amdgcn_readfirstlane(tap_soffB + chunk * 128);
+  };
 
   // ---- fragments (as in the glds2 kernel: lane half h reads k = 8g + 4h .. +3 of group g; MFMA j contracts k = {8g + j, 8g + 4 + j})
   const float* fa[4];
@@ -210,8 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
 
   // one K step: 64 MFMAs on stage STG_M; FIRST: the accumulators start from zero (C operand = 0, no clears);
   // DMA: the pieces of another step go out between the MFMAs into stage STG_M ^ 1 (one per 8 MFMAs)
-  auto kstep = [&](auto stgm_c, auto first_c, auto dma_c, auto pf_c, const float* ab, int abytes, const float* bb, int soff, bool do_dma,
-                   bool do_pf) __attribute__((always_inline)) {
+  auto kstep = [&](auto stgm_c, auto first_c, auto dma_c, auto pf_c, bool do_dma, bool do_pf) __attribute__((always_inline)) {
     constexpr int STG_M = decltype(stgm_c)::value, PF = decltype(pf_c)::value;   // PF: 0 none, 1 / 2: first / second half of the tile's epilogue operands
     constexpr bool FIRST = decltype(first_c)::value, DMA = decltype(dma_c)::value;
     using SD = std::integral_constant<int, STG_M ^ 1>;
@@ -265,7 +358,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
           if constexpr (fire) {
             if (do_dma) {
               __builtin_amdgcn_sched_barrier(0);
-              dma_piece(SD{}, std::integral_constant<int, piece>{}, ab, abytes, bb, soff);
+              dma_piece(SD{}, std::integral_constant<int, piece>{});
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -415,7 +508,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   // static split a block that cannot become resident — its CU is shared with another stream's kernel, e.g. RCCL during an
   // overlapped all-reduce — would start its whole share only after another block has finished: twice the launch time; with the
   // queues it finds them (nearly) empty.
-  const int npairs = K >> 6;                             // K steps of 32, two per iteration (K is a multiple of 64)
+  const int hp = K >> 6;                                 // pairs of 32-wide K steps per tap (Ci is a multiple of 64)
+  const int npairs = (GATHER ? p.ntaps : 1) * hp;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using T_ = std::true_type;
@@ -449,33 +543,44 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
     has = id < tiles;
   }
 
+  // K steps of a tile: (tap, 32-channel chunk), chunk fastest; `hp` pairs of steps per tap, `npairs` per tile. The DMA of step
+  // s + 1 goes out during step s: the even step of a pair carries its odd step's (same tap), the odd step carries the next pair's
+  // even step — which may belong to the next tap (set_tap first) or to the next tile (aim_tile + set_tap(0) first).
   bool pending = false;
   int pmt = 0, pnt = 0;
-  if (has) dma_all(I0{}, a_base(mt), a_bytes(mt), b_base(nt), 0);
+  if (has) {
+    aim_tile(mt, nt);
+    set_tap(0);
+    aim_step(0);
+    dma_all(I0{});
+  }
   while (true) {
     unsigned ticket = 0u;
     if (has) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step 0 of this tile has landed (and the previous tile's stores are out,
       __syncthreads();                                   //  its prefetched epilogue operands are in their registers)
-      dma_all(I1{}, a_base(mt), a_bytes(mt), b_base(nt), 128);
+      aim_step(1);
+      dma_all(I1{});
       if (dyn && tid == 0) ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (pending) epilogue1(pmt, pnt);
     if (!has) break;
     pre_tile(mt, nt);
-    kstep(I0{}, T_{}, F_{}, P1{}, nullptr, 0, nullptr, 0, false, npairs == 1);
+    kstep(I0{}, T_{}, F_{}, P1{}, false, npairs == 1);
     int nid = id + W;
     int nmt = mt + dm, nnt = nt + dn;
     if (nnt >= gridN) { nnt -= gridN; ++nmt; }
     bool nhas = nid < tiles;
+    int ti = 0, cp = 0;                                  // tap and pair-within-tap of pair `pr`
     for (int pr = 0; pr < npairs; ++pr) {
       const bool last = pr + 1 == npairs;
       if (pr > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        kstep(I0{}, F_{}, T_{}, P1{}, a_base(mt), a_bytes(mt), b_base(nt), (2 * pr + 1) * 128, true, last);
+        aim_step(2 * cp + 1);
+        kstep(I0{}, F_{}, T_{}, P1{}, true, last);
       }
-      if (pr == 0 && dyn && tid == 0) *nxt = (int)ticket;   // (the compiler waits for the atomic's return here: it is older than the stores)
+      if (pr == 0 && dyn && tid == 0) *nxt = (int)ticket;
       // (Tried and dropped: `s_waitcnt vmcnt(NST)` + a bare s_barrier here after a deferred epilogue, on the assumption that the
       // counter retires loads, LDS-DMA and stores strictly in issue order so that "all but the NST youngest" covers the DMA and
       // leaves the stores flying. It bought nothing measurable — the K = 64 launch ran 1.57 -> 1.62 ms — and an intermittent wrong
@@ -484,8 +589,23 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       __syncthreads();
       if (pr == 0 && dyn) nhas = ticket_tile(__builtin_amdgcn_readfirstlane(*nxt), nmt, nnt);
       if (pr == 0 && pending) epilogue2(pmt, pnt);
-      const int tmt = last ? nmt : mt, tnt = last ? nnt : nt;
-      kstep(I1{}, F_{}, T_{}, P2{}, a_base(tmt), a_bytes(tmt), b_base(tnt), last ? 0 : (2 * pr + 2) * 128, last ? nhas : true, last);
+      // aim the DMA of this odd step at the even step of the next pair
+      bool do_dma = true;
+      if (last) {
+        do_dma = nhas;
+        if (nhas) {
+          aim_tile(nmt, nnt);
+          set_tap(0);
+          aim_step(0);
+        }
+      } else if (cp + 1 == hp) {
+        set_tap(ti + 1);
+        aim_step(0);
+      } else {
+        aim_step(2 * cp + 2);
+      }
+      kstep(I1{}, F_{}, T_{}, P2{}, do_dma, last);
+      if (++cp == hp) { cp = 0; ++ti; }
     }
     pending = true;
     pmt = mt;
@@ -519,21 +639,34 @@ static int pw_cu_count() {
   return n;
 }
 
-bool pw_gemm_eligible(const GatherGemmParams& p) {
-  if (p.dtype != DT_F32 || p.ntaps != 1 || !p.simple_rows || p.os != 1 || p.T != 1) return false;
-  if (p.dy[0] != 0 || p.dx[0] != 0 || p.wt[0] != 0) return false;
-  if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 63)) return false;       // widths: multiples of 128 (four-wave tile) or of 64 (eight-wave tile)
+static bool pw_flags_ok(const GatherGemmParams& p) {
   switch (p.flags) {
-    case 0: case EPI_STATS: case EPI_ACCUM: case EPI_BNRED: break;
-    case EPI_MASKED_ADD: case EPI_BNRED | EPI_MASKED_ADD:
-      if (!p.addbits) return false;
-      break;
+    case 0: case EPI_STATS: case EPI_ACCUM: case EPI_BNRED: return true;
+    case EPI_MASKED_ADD: case EPI_BNRED | EPI_MASKED_ADD: return p.addbits != nullptr;
     default: return false;
   }
-  return true;
 }
 
-template <int BM, int BN, int WM, int WN>
+// 0: not for this kernel; 1: pointwise form (1x1 / stride 1: A rows are matrix rows); 2: gather form (dense OUTPUT rows: forward
+// of any geometry, dgrad of stride-1 layers)
+int pw_gemm_form(const GatherGemmParams& p) {
+  if (p.dtype != DT_F32 || p.os != 1 || p.ooy != 0 || p.oox != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 0;
+  if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 63) || !pw_flags_ok(p)) return 0;   // widths: multiples of 128 (four-wave tile) or 64 (eight-wave)
+  if (p.simple_rows && p.ntaps == 1 && p.T == 1 && p.dy[0] == 0 && p.dx[0] == 0 && p.wt[0] == 0) return 1;
+  if (p.simple_rows || p.ntaps < 1 || p.ntaps > MAX_TAPS) return 0;
+  // 32-bit offsets: a tile's rows span at most ceil(256 / (Hg Wg)) + 1 frames of the input; one weight tile [128][T][Ci]
+  if (p.Hi >= 16384 || p.Wi >= 16384 || p.Hi < 1 || p.Wi < 1 || p.Wg < 4 || p.Hg < 2) return 0;
+  const long long frame = (long long)p.Hi * p.Wi * p.Ci * 4;
+  const long long span = (256 / ((long long)p.Hg * p.Wg) + 2) * frame;
+  if (span >= (long long)BUF_OOB || 128LL * p.T * p.Ci * 4 >= (long long)BUF_OOB) return 0;
+  // four-wave gather form with the two register-hungriest epilogues (64 accumulators + 128 prefetched operands + the row state) would
+  // spill; no ResNet layer needs them (128-wide 3x3 / stride-1 dgrads with W <= 28 run the window kernel): left to the gather kernel
+  if ((p.Nc & 127) == 0 && (p.flags & EPI_BNRED) && ((p.flags & EPI_MASKED_ADD) || p.bn_bits)) return 0;
+  return 2;
+}
+bool pw_gemm_eligible(const GatherGemmParams& p) { return pw_gemm_form(p) != 0; }
+
+template <int BM, int BN, int WM, int WN, bool GA>
 static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;
   const int gridM = ceil_div(p_in.M, BM), gridN = p_in.Nc / BN;
@@ -548,8 +681,8 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
 #define LAUNCH_PW(E, YB)                                                                                                            \
   do {                                                                                                                             \
     static DynLdsOptIn oi;                                                                                                         \
-    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB>), LDS, "pw_gemm")) return e; \
-    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);                   \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA>), LDS, "pw_gemm")) return e; \
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);                   \
   } while (0)
   const bool yb = p.bn_bits != nullptr;
   switch (p.flags) {
@@ -558,10 +691,14 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
     case EPI_ACCUM: LAUNCH_PW(EPI_ACCUM, false); break;
     case EPI_MASKED_ADD: LAUNCH_PW(EPI_MASKED_ADD, false); break;
     case EPI_BNRED:
-      if (yb) LAUNCH_PW(EPI_BNRED, true); else LAUNCH_PW(EPI_BNRED, false);
+      if (!yb) LAUNCH_PW(EPI_BNRED, false);
+      else if constexpr (!(GA && NW == 4)) LAUNCH_PW(EPI_BNRED, true);
+      else { set_last_error("pw_gemm: form not built"); return 1; }
       break;
     case EPI_BNRED | EPI_MASKED_ADD:
-      if (yb) LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, true); else LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, false);
+      if constexpr (!(GA && NW == 4)) {
+        if (yb) LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, true); else LAUNCH_PW(EPI_BNRED | EPI_MASKED_ADD, false);
+      } else { set_last_error("pw_gemm: form not built"); return 1; }
       break;
     default: set_last_error("pw_gemm: unsupported epilogue flag combination %d", p.flags); return 1;
   }
@@ -570,7 +707,9 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
 }
 
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
-  return (p.Nc & 127) == 0 ? launch_pw_shape<128, 128, 2, 2>(p, s) : launch_pw_shape<256, 64, 4, 2>(p, s);
+  const bool wide = (p.Nc & 127) == 0;
+  if (pw_gemm_form(p) == 2) return wide ? launch_pw_shape<128, 128, 2, 2, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true>(p, s);
+  return wide ? launch_pw_shape<128, 128, 2, 2, false>(p, s) : launch_pw_shape<256, 64, 4, 2, false>(p, s);
 }
 
 }  // namespace r3m

@@ -475,7 +475,15 @@ def test_dgrad_epilogue_emits_bn_backward_partials(hip, case, mode, dtype):
     assert rc == 0, hip.r3m_last_error()
     dx = nchw(dxd.float().cpu())
     tol = 2e-5 if dtype == "fp32" else 2.0 ** -8
-    assert rel_err(dx.numpy(), dz.numpy())[0] < tol
+    e_dx = rel_err(dx.numpy(), dz.numpy())[0]
+    if not e_dx < tol:      # say WHERE: whole tiles missing (scheduling), single rows (addressing) or everything (arithmetic)
+        d = (nhwc(dx).double() - nhwc(dz.double())).abs().reshape(-1, Ci)
+        bad = (~torch.isfinite(d)) | (d > tol * float(dz.abs().max()))
+        rows = torch.nonzero(bad.any(1)).flatten()
+        cols = torch.nonzero(bad.any(0)).flatten()
+        pytest.fail(f"dgrad result: max-rel {e_dx}; non-finite {int((~torch.isfinite(d)).sum())}; {len(rows)} bad rows of {d.shape[0]} "
+                    f"(first {rows[:6].tolist()}, last {rows[-3:].tolist()}, 128-row tiles {sorted(set((rows // 128).tolist()))[:12]}); "
+                    f"{len(cols)} bad columns (first {cols[:6].tolist()}, last {cols[-3:].tolist()})")
     assert torch.isfinite(part).all(), "a partial row was not written"
     # the partials must describe the dz the kernel STORED (bf16: its own rounding of its own fp32 sum)
     g_dev = dx.double() * on

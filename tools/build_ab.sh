@@ -2,7 +2,8 @@
 # A/B builds for same-box comparisons (gitignored *.so; they travel with gpurun):
 #   r3m_amd/lib/libr3m_hip_base.so   = csrc/ of a git ref (default HEAD)             -> R3M_HIP_LIB=... python bench.py
 #   r3m_amd/lib/libr3m_hip_probes.so = the working tree with -DR3M_PROBES (environment switches live)
-# usage: tools/build_ab.sh [base-ref|none] [probes]
+#   r3m_amd/lib/libr3m_hip_<name>.so = the working tree with extra compiler flags (compile-time experiment switches)
+# usage: tools/build_ab.sh [base-ref|none] [probes | variant <name> <flags...>]
 set -e
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 REF="${1:-HEAD}"
@@ -25,3 +26,4 @@ if [ "$REF" != "none" ]; then
   build_tree "$T" "$ROOT/r3m_amd/lib/libr3m_hip_base.so"; rm -rf "$T"
 fi
 if [ "$2" = "probes" ]; then build_tree "$ROOT" "$ROOT/r3m_amd/lib/libr3m_hip_probes.so" -DR3M_PROBES; fi
+if [ "$2" = "variant" ]; then N="$3"; shift 3; build_tree "$ROOT" "$ROOT/r3m_amd/lib/libr3m_hip_$N.so" "$@"; fi

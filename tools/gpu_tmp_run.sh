@@ -1,7 +1,19 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for rep in 1 2 3 4; do
-  timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "conv_fwd_dgrad_wgrad or dgrad_epilogue" --timeout 600 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED" | tail -6
-done 2>&1 | tee gpurun_out/stress_ops.txt
+T=pw11
+rm -f gpurun_out/${T}_tests.txt
+for rep in 1 2 3; do
+( timeout 1500 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 1200 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|dgrad result" | tail -6 ) | tee -a gpurun_out/${T}_tests.txt
+done
+( timeout 1500 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_encoder.py tests/test_gpu_configs.py -m gpu -q --timeout 1200 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED" | tail -6 ) | tee -a gpurun_out/${T}_tests.txt
 for rep in 1 2; do
-  timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_fuzz.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED" | tail -6
-done 2>&1 | tee -a gpurun_out/stress_ops.txt
+  for v in base new nt sc1; do
+    LIB=$PWD/r3m_amd/lib/libr3m_hip.so; [ $v != new ] && LIB=$PWD/r3m_amd/lib/libr3m_hip_$v.so
+    R3M_HIP_LIB=$LIB timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 15 --prewarm-seconds 3 --launch-csv gpurun_out/${T}_launches_$v.csv 2>gpurun_out/${T}_$v.err > gpurun_out/${T}_c1_$v.json
+    python - <<PY
+import json
+j = json.load(open("gpurun_out/${T}_c1_$v.json"))
+print("$v rep $rep c1", j["value"], "frames/s", j["ms_per_step"], "ms", "class frac", j["roofline"]["frac"])
+PY
+  done
+done 2>&1 | tee gpurun_out/${T}_step_ab.txt
+for v in base new nt sc1; do python tools/launch_report.py gpurun_out/${T}_launches_$v.csv 15 > gpurun_out/${T}_launch_report_$v.txt 2>&1; done
