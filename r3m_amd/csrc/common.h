@@ -114,6 +114,7 @@ struct WgradParams {
   int dtype;           // DT_F32 / DT_BF16 storage of dY and X (out is always fp32)
   int gx;              // (co tile, ci tile, tap) blocks per split; the launch is 1-D: gx * splitK blocks
   int xcd;             // 1: XCD-aware block order — all blocks of one split (same dY / X rows) run on ONE XCD and share its L2
+  int debug;           // timing probes (probe builds, R3M_WG_DEBUG: 1 no DMA at all, 2 no X pieces, 4 no dY pieces); 0 in production
 };
 
 // EPI_BNRED request of a dgrad (engine.hip conv_dgrad_launch_br): the result is the dz of a BatchNorm whose input is Y (same
@@ -138,7 +139,7 @@ int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher wi
 // The engine hands the NEXT launch_gather_gemm of this thread 8 zeroed device counters (dynamic tile queues of the persistent
 // kernel: a block that finds its CU shared with another stream's kernel — RCCL during an overlapped all-reduce — simply takes
 // fewer tiles). Consumed (and cleared) by that launch whether or not it uses them; launches without it assign tiles statically.
-void gg_set_tile_counters(unsigned* ctr8);
+void gg_set_tile_counters(unsigned* ctr8, int sets = 1);
 int gg_set_dynamic_tiles(int on);        // diagnostic switch (r3m_debug_set_dynamic_tiles): 0 = ignore the counters, assign statically
 bool pw_gemm_eligible(const GatherGemmParams& p);          // conv_pw.hip: persistent kernel for 1x1 / stride-1 launches (fp32)
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s);

@@ -803,11 +803,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void conv3x3_wi
 
   auto issue_window_piece = [&](int q, int chunk, int buf) __attribute__((always_inline)) {
     const int i = wave_s + NW * q;
+    if (R3M_PROBE(p) & 8) return;                                // timing probe: no window DMA (stale LDS)
     if (i < nwp || i == NWP_ALL - 1)
       buf_dma16(a_base, a_bytes, wsm + buf * WIN_BYTES + i * 1024, woff[q], chunk * 128);
   };
   auto issue_b_piece = [&](int j, int tapk, int chunk, int stage) __attribute__((always_inline)) {
     const int wt = p.tap[tapk] >> 16;
+    if (R3M_PROBE(p) & 16) return;                               // timing probe: no weight DMA
     buf_dma16(p.B, b_bytes, bst + stage * BSTAGE + (wave_s * (BN / NW) + j * 8) * 128, bvoff[j], (wt * p.Ci + chunk * 32) * 4);
   };
 
@@ -932,14 +934,19 @@ double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem) {
 }
 
 static thread_local unsigned* t_tile_ctr = nullptr;
+static thread_local int t_tile_ctr_sets = 0;   // further sets of 8 counters behind t_tile_ctr (the parity-class launches of a stride-2 dgrad)
 static int g_dynamic_tiles = 1;          // diagnostic (tools/occupy_ab.py): plain int, written before launches from the same thread
-void gg_set_tile_counters(unsigned* ctr8) { t_tile_ctr = g_dynamic_tiles ? ctr8 : nullptr; }
+void gg_set_tile_counters(unsigned* ctr8, int sets) {
+  t_tile_ctr = g_dynamic_tiles ? ctr8 : nullptr;
+  t_tile_ctr_sets = t_tile_ctr ? sets : 0;
+}
 int gg_set_dynamic_tiles(int on) { const int old = g_dynamic_tiles; g_dynamic_tiles = on ? 1 : 0; return old; }
 
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
-  p.tile_ctr = t_tile_ctr;     // one launch only: a stride-2 dgrad's later parity launches, or the next layer, must not reuse them
-  t_tile_ctr = nullptr;
+  p.tile_ctr = t_tile_ctr;     // one set of counters serves ONE launch: the parity-class launches of a stride-2 dgrad take the next
+  if (t_tile_ctr && --t_tile_ctr_sets > 0) t_tile_ctr += 8;   // set each, and the next layer must not reuse any of them
+  else { t_tile_ctr = nullptr; t_tile_ctr_sets = 0; }
   if (p.dtype == DT_BF16) {
     {
       const int dbg = R3M_ENV_INT("R3M_GG_DEBUG", 0);
@@ -1324,6 +1331,9 @@ __global__ __launch_bounds__(256, (NT == 3 && BMt == 128) ? 2 : 1) void wgrad_gl
   // one DMA piece (pc < AJ: dY rows, else X rows of all NT taps) into `stage`
   auto issue_piece = [&](int stage, auto pc_c) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_c)::value;
+    if (R3M_PROBE(p) & 1) return;                       // timing probes (probe builds only; wrong results)
+    if ((R3M_PROBE(p) & 2) && pc >= AJ) return;
+    if ((R3M_PROBE(p) & 4) && pc < AJ) return;
     if constexpr (pc < AJ) {
       constexpr int j = pc;
       float* la = smem + stage * STAGE + wave_s * WR * BMt;
@@ -1907,6 +1917,7 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     p.interleave = il >= 0 ? il : (!p.simple_rows && wg_wide(p.Co, p.Ci));
     const int xc = R3M_ENV_INT("R3M_WG_XCD", 1);
     p.xcd = xc;
+    p.debug = R3M_ENV_INT("R3M_WG_DEBUG", 0);       // probe builds only (R3M_ENV_INT is the default in shipped builds)
   }
   const double flops = 2.0 * (double)p.M * (double)p.Co * (double)T * p.Ci;
   if (wg_wide(p.Co, p.Ci)) {

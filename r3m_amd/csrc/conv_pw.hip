@@ -110,7 +110,10 @@ __device__ __forceinline__ const float* pw_uniform_ptr(const float* q) {   // a 
 // rows of a matrix: every convolution whose OUTPUT rows are dense (forward of any k / stride / pad, dgrad of stride-1 layers). The
 // row -> pixel decode runs once per tile, a tap switch is ~7 vector instructions per staged row (offset + bounds test -> out-of-range
 // offset), everything else is the pointwise kernel.
-template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false, bool GATHER = false>
+// OSTR (with GATHER): the OUTPUT rows are strided too — pixel (gy os + ooy, gx os + oox) of an [N, Ho, Wo, Nc] tensor: the parity-class
+// launches of a stride-2 dgrad. The row -> pixel decode of the wave's 64 result rows runs once per tile (lane l = row l), the 8 TN
+// stores / operand loads take their row offsets from it with one ds_bpermute each, all at the start of the tile.
+template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false, bool GATHER = false, bool OSTR = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;        // waves; 32-column MFMA tiles per wave (2 or 1)
   static_assert(BM / WM == 64 && (TN == 1 || TN == 2) && (NW == 4 || NW == 8), "wave tile is 64 rows x 32 TN columns");
@@ -266,8 +269,29 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   const unsigned* t_gbits = nullptr;
   const unsigned* t_ybits = nullptr;
   int t_obytes = 0, t_bbytes = 0;
+  static_assert(!OSTR || (GATHER && !MADD && !YBITS), "strided output rows: gather form, no mask words");
+  unsigned orows[OSTR ? NST : 1];                         // OSTR: byte offset of this lane's row of store st (+ its columns); rows >= M: out of range
+  long long t_eo = 0;                                     // OSTR: element offset of (first frame of the tile, column n0)
   auto pre_tile = [&](int tmt, int tnt) __attribute__((always_inline)) {
-    if constexpr (PRE) {
+    if constexpr (OSTR) {
+      const int m0 = tmt * BM, n0 = tnt * BN;
+      const int hw = p.Hg * p.Wg;
+      const int nf = __builtin_amdgcn_readfirstlane(m0 / hw);       // first frame of the tile: 32-bit offsets are relative to it
+      const long long oframe = (long long)p.Ho * p.Wo * Nc;
+      t_eo = nf * oframe + n0;
+      const long long rest = ((long long)(p.N - nf) * oframe - n0) * 4;
+      t_obytes = __builtin_amdgcn_readfirstlane(rest < (long long)BUF_OOB ? (int)rest : (int)BUF_OOB);
+      const int m = m0 + wm * 64 + lane;                  // lane l decodes row l of the wave's 64
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int gy = rem / p.Wg, gx = rem - gy * p.Wg;
+      const unsigned mine = m < p.M ? (unsigned)(((((n - nf) * p.Ho + gy * p.os + p.ooy) * p.Wo + gx * p.os + p.oox) * Nc) * 4) : BUF_OOB;
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+        orows[st] = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (st * RPS + srow), (int)mine) + (unsigned)((wn * TN * 32 + scol) * 4);
+      if constexpr (ACC) t_gb = p.out + t_eo;
+      if constexpr (BNR) t_yb = p.bn_y + t_eo;
+    } else if constexpr (PRE) {
       const int m0 = tmt * BM, n0 = tnt * BN;
       const int rows_valid = min(BM, p.M - m0);
       const long long eo0 = (long long)m0 * Nc + n0;
@@ -286,9 +310,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       // being hoisted out of the tile loop (they do not fit the SGPR file and would be reloaded with v_readlane)
       int ncb = Nc * 4;
       asm volatile("" : "+s"(ncb));
-      const int so = (pc * RPS) * ncb;                    // first row of store pc
-      if constexpr (MADD || ACC) pg[pc] = pw_ld4(t_gb, t_obytes, vo4, so);
-      if constexpr (BNR) py[pc] = pw_ld4(t_yb, t_obytes, vo4, so);
+      const int so = OSTR ? 0 : (pc * RPS) * ncb;         // first row of store pc
+      const unsigned vo = OSTR ? orows[OSTR ? pc : 0] : vo4;
+      if constexpr (MADD || ACC) pg[pc] = pw_ld4(t_gb, t_obytes, vo, so);
+      if constexpr (BNR) py[pc] = pw_ld4(t_yb, t_obytes, vo, so);
       if constexpr (pc == 0) {
         if constexpr (MADD) {
           if constexpr (TN == 2) pgm = pw_ld2(t_gbits, t_bbytes, vow);
@@ -416,8 +441,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
     }
     const int rows_valid = min(BM, p.M - m0);
     const long long eo0 = (long long)m0 * Nc + n0;                  // element offset of the tile origin
-    const int obytes = ((rows_valid - 1) * Nc + BN) * 4;            // a lane's offset is inside iff its row is < rows_valid
-    float* ob = p.out + eo0;
+    const int obytes = OSTR ? t_obytes : ((rows_valid - 1) * Nc + BN) * 4;   // a lane's offset is inside iff its row is < rows_valid
+    float* ob = p.out + (OSTR ? t_eo : eo0);              // (OSTR: the tile's own values are still in place — pre_tile of the next tile comes after)
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, sc = s1, sh = s1;
     if constexpr (BNR) {
       const int col = n0 + wn * CW + scol;
@@ -447,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += ((nb >> e) & 1u) ? pg[st][e] : 0.f;
         }
-        if (!(R3M_PROBE(p) & 1)) pw_st4(ob, obytes, vo4, (st * RPS) * ncb, v);
+        if (!(R3M_PROBE(p) & 1)) pw_st4(ob, obytes, OSTR ? orows[OSTR ? st : 0] : vo4, OSTR ? 0 : (st * RPS) * ncb, v);
         if constexpr (BNR) {
           const f32x4 y = py[st];
           unsigned nb = 0u;
@@ -648,17 +673,26 @@ static bool pw_flags_ok(const GatherGemmParams& p) {
 }
 
 // 0: not for this kernel; 1: pointwise form (1x1 / stride 1: A rows are matrix rows); 2: gather form (dense OUTPUT rows: forward
-// of any geometry, dgrad of stride-1 layers)
+// of any geometry, dgrad of stride-1 layers); 3: gather form with strided output rows (a parity class of a stride-2 dgrad)
 int pw_gemm_form(const GatherGemmParams& p) {
-  if (p.dtype != DT_F32 || p.os != 1 || p.ooy != 0 || p.oox != 0 || p.Hg != p.Ho || p.Wg != p.Wo) return 0;
+  if (p.dtype != DT_F32) return 0;
+  const bool dense_out = p.os == 1 && p.ooy == 0 && p.oox == 0 && p.Hg == p.Ho && p.Wg == p.Wo;
   if ((p.Ci & 63) || p.Ci > 2048 || (p.Nc & 63) || !pw_flags_ok(p)) return 0;   // widths: multiples of 128 (four-wave tile) or 64 (eight-wave)
-  if (p.simple_rows && p.ntaps == 1 && p.T == 1 && p.dy[0] == 0 && p.dx[0] == 0 && p.wt[0] == 0) return 1;
+  if (dense_out && p.simple_rows && p.ntaps == 1 && p.T == 1 && p.dy[0] == 0 && p.dx[0] == 0 && p.wt[0] == 0) return 1;
   if (p.simple_rows || p.ntaps < 1 || p.ntaps > MAX_TAPS) return 0;
   // 32-bit offsets: a tile's rows span at most ceil(256 / (Hg Wg)) + 1 frames of the input; one weight tile [128][T][Ci]
   if (p.Hi >= 16384 || p.Wi >= 16384 || p.Hi < 1 || p.Wi < 1 || p.Wg < 4 || p.Hg < 2) return 0;
   const long long frame = (long long)p.Hi * p.Wi * p.Ci * 4;
   const long long span = (256 / ((long long)p.Hg * p.Wg) + 2) * frame;
   if (span >= (long long)BUF_OOB || 128LL * p.T * p.Ci * 4 >= (long long)BUF_OOB) return 0;
+  if (!dense_out) {
+    // strided output rows: every output pixel of the class inside the tensor, 32-bit offsets over the frames a tile spans, and the
+    // epilogues a stride-2 dgrad uses (plain, accumulate, BatchNorm-backward partials with the mask recomputed from y)
+    if (p.os < 1 || p.ooy < 0 || p.oox < 0 || (p.Hg - 1) * p.os + p.ooy >= p.Ho || (p.Wg - 1) * p.os + p.oox >= p.Wo) return 0;
+    if ((256 / ((long long)p.Hg * p.Wg) + 2) * (long long)p.Ho * p.Wo * p.Nc * 4 >= (long long)BUF_OOB) return 0;
+    if (p.flags != 0 && p.flags != EPI_ACCUM && !(p.flags == EPI_BNRED && !p.bn_bits)) return 0;
+    return 3;
+  }
   // four-wave gather form with the two register-hungriest epilogues (64 accumulators + 128 prefetched operands + the row state) would
   // spill; no ResNet layer needs them (128-wide 3x3 / stride-1 dgrads with W <= 28 run the window kernel): left to the gather kernel
   if ((p.Nc & 127) == 0 && (p.flags & EPI_BNRED) && ((p.flags & EPI_MASKED_ADD) || p.bn_bits)) return 0;
@@ -666,7 +700,7 @@ int pw_gemm_form(const GatherGemmParams& p) {
 }
 bool pw_gemm_eligible(const GatherGemmParams& p) { return pw_gemm_form(p) != 0; }
 
-template <int BM, int BN, int WM, int WN, bool GA>
+template <int BM, int BN, int WM, int WN, bool GA, bool OS = false>
 static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;
   const int gridM = ceil_div(p_in.M, BM), gridN = p_in.Nc / BN;
@@ -681,10 +715,19 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
 #define LAUNCH_PW(E, YB)                                                                                                            \
   do {                                                                                                                             \
     static DynLdsOptIn oi;                                                                                                         \
-    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA>), LDS, "pw_gemm")) return e; \
-    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);                   \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA, OS>), LDS, "pw_gemm")) return e; \
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA, OS>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);               \
   } while (0)
   const bool yb = p.bn_bits != nullptr;
+  if constexpr (OS) {                                                 // strided output rows: the three epilogues pw_gemm_form admits
+    switch (p.flags) {
+      case 0: LAUNCH_PW(0, false); return 0;
+      case EPI_ACCUM: LAUNCH_PW(EPI_ACCUM, false); return 0;
+      case EPI_BNRED: if (!yb) { LAUNCH_PW(EPI_BNRED, false); return 0; }
+    }
+    set_last_error("pw_gemm: form not built");
+    return 1;
+  } else {
   switch (p.flags) {
     case 0: LAUNCH_PW(0, false); break;
     case EPI_STATS: LAUNCH_PW(EPI_STATS, false); break;
@@ -702,13 +745,16 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
       break;
     default: set_last_error("pw_gemm: unsupported epilogue flag combination %d", p.flags); return 1;
   }
-#undef LAUNCH_PW
   return 0;
+  }
+#undef LAUNCH_PW
 }
 
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   const bool wide = (p.Nc & 127) == 0;
-  if (pw_gemm_form(p) == 2) return wide ? launch_pw_shape<128, 128, 2, 2, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true>(p, s);
+  const int form = pw_gemm_form(p);
+  if (form == 3) return wide ? launch_pw_shape<128, 128, 2, 2, true, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true, true>(p, s);
+  if (form == 2) return wide ? launch_pw_shape<128, 128, 2, 2, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true>(p, s);
   return wide ? launch_pw_shape<128, 128, 2, 2, false>(p, s) : launch_pw_shape<256, 64, 4, 2, false>(p, s);
 }
 

@@ -63,7 +63,7 @@ struct Plan {
   long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
   // arena offsets (floats)
   long long col_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
-  long long ctr_off = 0;    // [2][convs][8] unsigned: per-XCD tile queues of the persistent 1x1 kernel, forward / backward launch of each conv
+  long long ctr_off = 0;    // [convs][8] + [convs][4][8] unsigned: per-XCD tile queues of the persistent kernel — the forward launch of each conv, and the (up to four: stride-2 parity classes) backward launches
   long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
   long long arena_floats = 0;
   long long gmax = 0;
@@ -235,7 +235,7 @@ Plan* plan_create(int size, int F, int dtype) {
   }
   if (dtype == DT_BF16) P.w16_off = take((P.n_params + 1) / 2);
   P.wgp_off = take(wgp_max);
-  P.ctr_off = take(2LL * (long long)P.convs.size() * 8);
+  P.ctr_off = take(5LL * (long long)P.convs.size() * 8);
   P.gmax = gmax;
   for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
   P.arena_floats = off;
@@ -537,9 +537,10 @@ static int dgrad(Ctx& c, const ConvSpec& L, const float* dY, float* dX, int flag
   float* Wt = c.dt == DT_BF16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c.arena + c.P.wt_off) + L.wt_off)
                               : c.arena + c.P.wt_off + L.wt_off;
   if (fused_rows_out) *fused_rows_out = 0;
-  gg_set_tile_counters(reinterpret_cast<unsigned*>(c.arena + c.P.ctr_off) + (c.P.convs.size() + (&L - c.P.convs.data())) * 8);   // backward half
+  gg_set_tile_counters(reinterpret_cast<unsigned*>(c.arena + c.P.ctr_off) + (c.P.convs.size() + 4 * (&L - c.P.convs.data())) * 8, 4);   // backward part
   // 1x1 stride-2 dgrads leave three of four parity classes without taps (plain zero / no-op launches): not fused
   const bool fuse = bn_of && fused_rows_out && c.P.fuse_bnred && !(L.stride == 2 && L.k == 1);
+  struct DropCounters { ~DropCounters() { gg_set_tile_counters(nullptr, 0); } } drop;   // sets this layer did not use stay unused
   if (!fuse)
     return conv_dgrad_launch(dY, Wt, dX, add0, nullptr, addbits, c.P.F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, flags, c.dt, c.s);
   BnRedArgs br{c.arena + bn_of->Y_off, bn_bits, c.arena + bn_of->coef_off + 2LL * bn_of->Co, c.arena + bn_of->coef_off + 3LL * bn_of->Co,
@@ -602,7 +603,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   P.next_stage = -2;           // poisoned while in flight: after a failed call only stage 0 (a restart) is accepted
   TRY(side_init(P));
   if (stage_begin == 0) {       // the weights are final since the last optimizer step: all dgrad weight images in one launch
-    if (hipMemsetAsync(arena + P.ctr_off + P.convs.size() * 8, 0, P.convs.size() * 8 * sizeof(unsigned), s) != hipSuccess) {
+    if (hipMemsetAsync(arena + P.ctr_off + P.convs.size() * 8, 0, 4 * P.convs.size() * 8 * sizeof(unsigned), s) != hipSuccess) {
       set_last_error("resnet_backward: cannot reset the tile queues");
       return 1;
     }

@@ -32,6 +32,8 @@ CONV_CASES = [
     # partial last row tile, one / two / four K-step pairs per tile
     (24, 56, 64, 256, 1, 1, 0), (23, 56, 64, 128, 1, 1, 0), (21, 56, 128, 256, 1, 1, 0), (85, 28, 256, 128, 1, 1, 0),
     (24, 56, 256, 64, 1, 1, 0), (23, 56, 128, 64, 1, 1, 0),     # ... and its eight-wave 256 x 64 tile (64-channel outputs)
+    # ... its gather form (3x3 / strided forward, stride-1 dgrad) and the strided-output form (parity classes of a stride-2 dgrad)
+    (45, 28, 128, 128, 3, 1, 1), (90, 56, 128, 128, 3, 2, 1), (91, 56, 64, 64, 3, 2, 1), (90, 56, 128, 256, 1, 2, 0),
 ]
 
 
@@ -412,7 +414,9 @@ BNRED_CASES = [(2, 56, 64, 256, 1, 1, 0), (2, 56, 256, 64, 1, 1, 0), (2, 28, 128
                (3, 14, 256, 256, 3, 1, 1), (5, 7, 2048, 512, 1, 1, 0), (2, 56, 64, 128, 3, 2, 1), (3, 9, 64, 64, 3, 1, 1),
                (7, 5, 160, 64, 1, 1, 0), (2, 13, 32, 64, 3, 2, 1),
                # persistent 1x1 kernel: several tiles per worker, partial last row tile (dgrad: GEMM N = Ci, K = Co)
-               (24, 56, 256, 64, 1, 1, 0), (21, 56, 256, 128, 1, 1, 0), (24, 56, 64, 256, 1, 1, 0), (23, 56, 64, 128, 1, 1, 0)]
+               (24, 56, 256, 64, 1, 1, 0), (21, 56, 256, 128, 1, 1, 0), (24, 56, 64, 256, 1, 1, 0), (23, 56, 64, 128, 1, 1, 0),
+               # ... strided-output form: a stride-2 dgrad's parity classes, more tiles than workers
+               (90, 56, 128, 128, 3, 2, 1), (91, 56, 64, 64, 3, 2, 1)]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
