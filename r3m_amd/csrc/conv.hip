@@ -1929,7 +1929,9 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<128, 128>), dim3(tiles * splitK), dim3(256), 0, s, p);
     else
 #endif
-    if (wg_rows(p.KW)) {   // 3-wide kernels: one block per kernel row (three taps), K steps of 16 rows
+    if (wg_rows(p.KW) && R3M_ENV_INT("R3M_WG_WIN", 1) && wgrad_rowwin_eligible(p)) {   // 3x3 "same" convolutions: shared input window (wgrad_win.hip)
+      if (int e = launch_wgrad_rowwin(p, splitK, s)) return e;
+    } else if (wg_rows(p.KW)) {   // 3-wide kernels: one block per kernel row (three taps), K steps of 16 rows
       p.gx = ceil_div(p.Co, 128) * p.tilesN * p.KH;
       hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 16, 3, 1>), dim3(p.gx * splitK), dim3(256), 0, s, p);
     } else
@@ -1951,7 +1953,9 @@ int launch_wgrad(const WgradParams& p0, int splitK, hipStream_t s) {
     if (!wg_use_glds()) hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3(tiles * splitK), dim3(256), 0, s, p);
     else
 #endif
-    if (wg_rows(p.KW)) {
+    if (wg_rows(p.KW) && R3M_ENV_INT("R3M_WG_WIN", 1) && wgrad_rowwin_eligible(p)) {
+      if (int e = launch_wgrad_rowwin(p, splitK, s)) return e;
+    } else if (wg_rows(p.KW)) {
       p.gx = ceil_div(p.Co, 64) * p.tilesN * p.KH;
       hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 16, 3, 0>), dim3(p.gx * splitK), dim3(256), 0, s, p);
     } else
