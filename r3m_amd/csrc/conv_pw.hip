@@ -707,7 +707,7 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   const long long tiles_ll = (long long)gridM * gridN;
   R3M_REQUIRE(tiles_ll < 0x7FFFFFFFLL, "pw_gemm: too many tiles");
   const int tiles = (int)tiles_ll;
-  const int slots = (NW == 4 ? 2 : 1) * pw_cu_count();               // resident blocks: two four-wave blocks or one eight-wave block per CU
+  const int slots = (NW == 4 ? (BN == 64 ? 3 : 2) : 1) * pw_cu_count();   // resident blocks: two four-wave blocks or one eight-wave block per CU (experiment: three 128 x 64 blocks)
   const int W = tiles < slots ? tiles : slots;
   GatherGemmParams p = p_in;
   if (W < 64 || gridM < 64) p.tile_ctr = nullptr;                     // small launches: every queue needs blocks AND panels; static split
@@ -753,6 +753,11 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   const bool wide = (p.Nc & 127) == 0;
   const int form = pw_gemm_form(p);
+#ifdef R3M_PROBES
+  // experiment (probe builds): 64-wide pointwise launches on a 128 x 64 tile, four waves, three blocks per CU — more bytes in flight
+  // per CU than the eight-wave tile's one block. Its statistics rows are per 128 result rows: the caller must size for that.
+  if (form == 1 && !wide && R3M_ENV_INT("R3M_PW_N128", 0)) return launch_pw_shape<128, 64, 2, 2, false>(p, s);
+#endif
   if (form == 3) return wide ? launch_pw_shape<128, 128, 2, 2, true, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true, true>(p, s);
   if (form == 2) return wide ? launch_pw_shape<128, 128, 2, 2, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true>(p, s);
   return wide ? launch_pw_shape<128, 128, 2, 2, false>(p, s) : launch_pw_shape<256, 64, 4, 2, false>(p, s);

@@ -26,7 +26,7 @@ for spec in sys.argv[2:]:
     flops = 2.0 * N * Ho * Ho * Co * Ci * k * k
     if mode == "fwd":
         rows = L.r3m_conv2d_stats_rows(N, H, H, Co, k, s, p)
-        stats = torch.empty((rows, 2, Co), device="cuda")
+        stats = torch.empty((2 * rows + 2, 2, Co), device="cuda")   # (room for experiments with finer statistics rows)
         fn = lambda: L.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, dt, st)
     elif mode in ("dgradbn", "dgradbnres"):
         dy = torch.randn_like(y)
