@@ -603,7 +603,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         aim_step(2 * cp + 1);
-        kstep(I0{}, F_{}, T_{}, P1{}, true, last);
+        if (R3M_PROBE(p) & 32) {                          // probe: this step's DMA pieces in one burst before its MFMAs
+          dma_all(I1{});
+          kstep(I0{}, F_{}, F_{}, P1{}, false, last);
+        } else {
+          kstep(I0{}, F_{}, T_{}, P1{}, true, last);
+        }
       }
       if (pr == 0 && dyn && tid == 0) *nxt = (int)ticket;
       // (Tried and dropped: `s_waitcnt vmcnt(NST)` + a bare s_barrier here after a deferred epilogue, on the assumption that the
@@ -629,7 +634,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       } else {
         aim_step(2 * cp + 2);
       }
-      kstep(I1{}, F_{}, T_{}, P2{}, do_dma, last);
+      if (R3M_PROBE(p) & 32) {
+        if (do_dma) dma_all(I0{});
+        kstep(I1{}, F_{}, F_{}, P2{}, false, last);
+      } else {
+        kstep(I1{}, F_{}, T_{}, P2{}, do_dma, last);
+      }
       if (++cp == hp) { cp = 0; ++ti; }
     }
     pending = true;
