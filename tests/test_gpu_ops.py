@@ -34,6 +34,9 @@ CONV_CASES = [
     (24, 56, 256, 64, 1, 1, 0), (23, 56, 128, 64, 1, 1, 0),     # ... and its eight-wave 256 x 64 tile (64-channel outputs)
     # ... its gather form (3x3 / strided forward, stride-1 dgrad) and the strided-output form (parity classes of a stride-2 dgrad)
     (45, 28, 128, 128, 3, 1, 1), (90, 56, 128, 128, 3, 2, 1), (91, 56, 64, 64, 3, 2, 1), (90, 56, 128, 256, 1, 2, 0),
+    # shared-window 3x3 weight gradient (wgrad_win.hip): image rows shorter than a K step's 32 rows by a lot (seven row segments per
+    # step), longer than it (steps without a row start), and a width of 4
+    (7, 5, 64, 64, 3, 1, 1), (3, 33, 64, 128, 3, 1, 1), (5, 4, 128, 128, 3, 1, 1),
 ]
 
 

@@ -1,9 +1,15 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
-export R3M_HIP_LIB=$PWD/r3m_amd/lib/libr3m_hip_probes.so
-{
-for d in 0 32; do
-  echo "== R3M_GG_DEBUG=$d (32: DMA pieces of a K step in one burst before its MFMAs)"
-  R3M_GG_DEBUG=$d python tools/conv_bench.py fwd 1280,56,256,64,1,1,0 1280,56,64,256,1,1,0 1280,28,128,512,1,1,0 1280,28,512,128,1,1,0 1280,14,256,1024,1,1,0 1280,14,1024,256,1,1,0 1280,7,512,2048,1,1,0 1280,56,64,64,3,1,1 1280,28,256,512,1,2,0 2>/dev/null
-  R3M_GG_DEBUG=$d python tools/conv_bench.py dgradbn 1280,56,64,256,1,1,0 1280,56,256,64,1,1,0 1280,28,512,128,1,1,0 2>/dev/null
-done
-} 2>&1 | tee gpurun_out/cluster_probe.txt
+T=r04_final_hot
+# the driver's measurement conditions: 10 s pre-warm, 25 timed steps (bench.py defaults), round-3 build vs final build, interleaved
+for rep in 1 2; do
+  for v in base new; do
+    LIB=$PWD/r3m_amd/lib/libr3m_hip.so; [ $v != new ] && LIB=$PWD/r3m_amd/lib/libr3m_hip_$v.so
+    R3M_HIP_LIB=$LIB timeout 600 python bench.py --no-cpu-baseline --no-secondary 2>gpurun_out/${T}_$v.err > gpurun_out/${T}_c1_$v.json
+    python - <<PY
+import json
+j = json.load(open("gpurun_out/${T}_c1_$v.json"))
+print("$v rep $rep c1", j["value"], "frames/s", j["ms_per_step"], "ms", "class frac", j["roofline"]["frac"], "whole", j["roofline"]["whole_step_frac"], "steps", j["steps"])
+PY
+  done
+done 2>&1 | tee gpurun_out/${T}_step_ab.txt
+( timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 600 -p no:cacheprovider -k "H5_64to64 or H33_64to128 or H4_128to128" 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -6 ) | tee gpurun_out/${T}_newcases.txt
