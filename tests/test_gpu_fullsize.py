@@ -170,6 +170,40 @@ def _per_tensor_err(m, g_a, g_b):
     return worst, worst_k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_headline_size_train_step_is_bit_reproducible(hip, precision):
+    """Round 4: the persistent convolution kernels take their tiles from per-XCD atomic queues, so WHICH block computes a tile
+    (and in which order a block's tiles run) differs from launch to launch. Every result element, BatchNorm partial row and
+    weight-gradient slab is still a function of its tile alone, combined in a fixed order: two train-mode forward + backward
+    passes on the same 1280 frames must give bit-identical embeddings, running statistics and parameter gradients."""
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    from r3m_amd import R3M
+    torch.manual_seed(5)
+    m = R3M("cuda", 1e-4, 1024, size=50, langweight=0.0, tcnweight=1.0, precision=precision).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randint(0, 256, (F_FULL, 3, 224, 224), generator=g, device=DEV, dtype=torch.int32).float()
+    dh = torch.rand((F_FULL, m.outdim), generator=g, device=DEV) - 0.3
+    m.train()
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        m.load_state_dict(state0)                      # same running statistics going in
+        m.encoder_opt.zero_grad()
+        h = m(x)
+        hc = h.detach().clone()
+        h.backward(dh)
+        runs.append((hc, m.convnet.flat_grads().clone(), {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+        del h
+    assert torch.isfinite(runs[0][1]).all()
+    assert torch.equal(runs[0][0], runs[1][0]), "embeddings differ between two identical passes"
+    assert torch.equal(runs[0][1], runs[1][1]), "parameter gradients differ between two identical passes"
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), f"{k} differs between two identical passes"
+    del m, x
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("size,precision,F,chunk", [(50, "fp32", 1280, 160), (34, "bf16", 2560, 320)])
 def test_headline_backward_equals_sum_of_chunk_backwards(hip, size, precision, F, chunk):
     """a NUMERIC reference for the backward at the bench sizes (BASELINE configs[1]: ResNet-50 fp32 1280
