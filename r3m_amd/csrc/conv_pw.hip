@@ -113,7 +113,10 @@ __device__ __forceinline__ const float* pw_uniform_ptr(const float* q) {   // a 
 // OSTR (with GATHER): the OUTPUT rows are strided too — pixel (gy os + ooy, gx os + oox) of an [N, Ho, Wo, Nc] tensor: the parity-class
 // launches of a stride-2 dgrad. The row -> pixel decode of the wave's 64 result rows runs once per tile (lane l = row l), the 8 TN
 // stores / operand loads take their row offsets from it with one ds_bpermute each, all at the start of the tile.
-template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false, bool GATHER = false, bool OSTR = false>
+// BURST: the DMA pieces of a K step leave in one burst before its MFMAs instead of one per eight MFMAs. Spreading hides their issue
+// cost under the MFMAs; the burst gives the loads a whole K step to land. Measured per shape (profiles/r04_cluster_dma_ab.txt): the
+// burst wins 2-3 % on contracting launches (K >= 2 N: their A stream is the larger side) and loses 2-6 % on expanding ones; see pw_burst.
+template <int BM, int BN, int WM, int WN, int EPI, bool YBITS = false, bool GATHER = false, bool OSTR = false, bool BURST = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_kernel(const GatherGemmParams p, const int tiles, const int gridN) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;        // waves; 32-column MFMA tiles per wave (2 or 1)
   static_assert(BM / WM == 64 && (TN == 1 || TN == 2) && (NW == 4 || NW == 8), "wave tile is 64 rows x 32 TN columns");
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         aim_step(2 * cp + 1);
-        if (R3M_PROBE(p) & 32) {                          // probe: this step's DMA pieces in one burst before its MFMAs
+        if (BURST || (R3M_PROBE(p) & 32)) {               // (probe 32: burst in every variant)
           dma_all(I1{});
           kstep(I0{}, F_{}, F_{}, P1{}, false, last);
         } else {
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       } else {
         aim_step(2 * cp + 2);
       }
-      if (R3M_PROBE(p) & 32) {
+      if (BURST || (R3M_PROBE(p) & 32)) {
         if (do_dma) dma_all(I0{});
         kstep(I1{}, F_{}, F_{}, P2{}, false, last);
       } else {
@@ -710,6 +713,14 @@ int pw_gemm_form(const GatherGemmParams& p) {
 }
 bool pw_gemm_eligible(const GatherGemmParams& p) { return pw_gemm_form(p) != 0; }
 
+// Launches that run the burst variant: contracting ones (K >= 2 N) on the eight-wave tile — ONE block per CU, so no co-resident block
+// covers a late DMA piece: -2.4 % on the 256 -> 64 launches, -0.7 % on the 64-channel 3x3 in the step; on the four-wave tile (two
+// blocks per CU) the two issue orders measured the same within noise. Built for the three epilogues those launches use.
+static bool pw_burst(const GatherGemmParams& p) {
+  const long long ktot = (long long)(p.simple_rows ? 1 : p.ntaps) * p.Ci;
+  return (p.Nc & 127) != 0 && ktot >= 2LL * p.Nc && (p.flags == EPI_STATS || p.flags == 0 || (p.flags == EPI_BNRED && !p.bn_bits));
+}
+
 template <int BM, int BN, int WM, int WN, bool GA, bool OS = false>
 static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;
@@ -728,6 +739,12 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
     if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA, OS>), LDS, "pw_gemm")) return e; \
     hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, YB, GA, OS>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);               \
   } while (0)
+#define LAUNCH_PW_BURST(E)                                                                                                          \
+  do {                                                                                                                             \
+    static DynLdsOptIn oi;                                                                                                         \
+    if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(pw_gemm_kernel<BM, BN, WM, WN, E, false, GA, false, true>), LDS, "pw_gemm")) return e; \
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, BN, WM, WN, E, false, GA, false, true>), dim3(W), dim3(NW * 64), LDS, s, p, tiles, gridN);   \
+  } while (0)
   const bool yb = p.bn_bits != nullptr;
   if constexpr (OS) {                                                 // strided output rows: the three epilogues pw_gemm_form admits
     switch (p.flags) {
@@ -738,6 +755,13 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
     set_last_error("pw_gemm: form not built");
     return 1;
   } else {
+  if constexpr (NW == 8) if (pw_burst(p)) {
+    switch (p.flags) {
+      case 0: LAUNCH_PW_BURST(0); return 0;
+      case EPI_STATS: LAUNCH_PW_BURST(EPI_STATS); return 0;
+      case EPI_BNRED: LAUNCH_PW_BURST(EPI_BNRED); return 0;
+    }
+  }
   switch (p.flags) {
     case 0: LAUNCH_PW(0, false); break;
     case EPI_STATS: LAUNCH_PW(EPI_STATS, false); break;
@@ -758,6 +782,7 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   return 0;
   }
 #undef LAUNCH_PW
+#undef LAUNCH_PW_BURST
 }
 
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
