@@ -630,8 +630,6 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
     TRY(launch_transpose_w_all(params, arena + P.wt_off, P.d_wt_tab, P.d_wt_tile0, (int)P.wt_tab.size(), P.wt_tile0.back(), P.dtype, s));
   }
   const bool side_on = P.use_side && P.side;
-  // order of a layer's two gradient GEMMs on the main stream (both read the dY the BatchNorm backward just wrote)
-  const bool wg_first = !side_on && R3M_ENV_INT("R3M_WG_FIRST", 0) != 0;
   Ctx cs = c;                       // context whose launches go to the side stream
   cs.s = side_on ? P.side : s;
   const int F = P.F;
@@ -715,9 +713,8 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         TRY(acquire_A(ai));
         TRY(bn_backward(c, L, dz, zmask, dY, dz_fused));     // HBM-bound: overlaps the previous layer's wgrad
         TRY(wait_wgrads());
-        if (wg_first) TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
         TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr, &Lprev, nullptr, &dz_fused));   // Gb = dz of Lprev's BatchNorm + its partials
-        if (!wg_first) TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
+        TRY(wgrad_async(L, arena + Lprev.Z_off, dY, ai));
         dz = Gb; zmask = nullptr;   // Gb is consumed by the next bn_backward before a later dgrad rewrites it
       }
       const ConvSpec& L1 = P.convs[B.conv[0]];
@@ -727,23 +724,20 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       TRY(wait_wgrads());
       if (B.ds >= 0) {
         const ConvSpec& Ld = P.convs[B.ds];
-        if (wg_first) TRY(wgrad_async(L1, Xin, dY1, ai));
         TRY(dgrad(c, L1, dY1, Gc, 0, nullptr, nullptr));
-        if (!wg_first) TRY(wgrad_async(L1, Xin, dY1, ai));
+        TRY(wgrad_async(L1, Xin, dY1, ai));
         int ad;
         float* dYd = next_A(&ad);
         TRY(acquire_A(ad));
         TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1); always the stand-alone reduce (second consumer of dOut)
         TRY(wait_wgrads());
-        if (wg_first) TRY(wgrad_async(Ld, Xin, dYd, ad));
         TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
-        if (!wg_first) TRY(wgrad_async(Ld, Xin, dYd, ad));
+        TRY(wgrad_async(Ld, Xin, dYd, ad));
       } else {
         // Gc = dgrad + masked residual gradient = the previous block's COMPLETE output gradient: also emit the partials of the
         // BatchNorm that will consume it (the previous block's last one, masked by that block's output bits)
-        if (wg_first) TRY(wgrad_async(L1, Xin, dY1, ai));
         TRY(dgrad(c, L1, dY1, Gc, EPI_MASKED_ADD, dOut, Out, Lprev_last, prev_bits, &P.dout_fused_rows));
-        if (!wg_first) TRY(wgrad_async(L1, Xin, dY1, ai));
+        TRY(wgrad_async(L1, Xin, dY1, ai));
       }
       // C becomes the gradient of the previous block's output; the old D is free (only the main stream ever read it)
       const int t = role[0]; role[0] = role[4]; role[4] = t;
