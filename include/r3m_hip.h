@@ -34,6 +34,13 @@ int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm1
 int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_t stream);
 /* Diagnostic: 0 = the encoder's persistent-kernel launches assign tiles statically, 1 (default) = per-XCD tile queues. Returns the old value. */
 int r3m_debug_set_dynamic_tiles(int on);
+/* Diagnostic, runs without a GPU: which kernel family the gather-GEMM dispatch (csrc/conv.hip gg_route) picks for every launch of one
+   convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual
+   join, 64 BatchNorm-backward partials, mask_bits = 1: their ReLU mask comes as bits) — nothing is launched. routes[i]: 1 = 3x3 window
+   kernel, 11 / 12 / 13 = persistent kernel (pointwise / gather / strided-output form), 20 = 16-wide-K kernel, 21 = gather kernel,
+   22 = generic kernel, 30 = bf16 path. Returns the number of launches (a stride-2 dgrad has up to four), -1 on error. */
+int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
+                         int* routes, int cap);
 void r3m_profile_enable(int on);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
 int r3m_profile_collect_bytes(double* bytes);     /* algorithmic HBM bytes per class (operands + results once) of the launches of the last collect() */

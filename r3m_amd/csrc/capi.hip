@@ -184,6 +184,24 @@ int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_
   return r3m::check_launch("debug_occupy");
 }
 int r3m_debug_set_dynamic_tiles(int on) { return r3m::gg_set_dynamic_tiles(on); }
+int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
+                         int* routes, int cap) {
+  R3M_REQUIRE(routes && cap >= 1, "debug_conv_route: routes buffer");
+  // no launch happens: the pointers only have to look like the ones the epilogue flags ask for
+  const unsigned* some_bits = reinterpret_cast<const unsigned*>(static_cast<uintptr_t>(64));
+  r3m::gg_route_record_begin(routes, cap);
+  int rc;
+  if (!dgrad) {
+    rc = r3m::conv_forward_launch(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Ci, Co, k, stride, pad, flags, dtype, nullptr);
+  } else {
+    r3m::BnRedArgs br{nullptr, mask_bits ? some_bits : nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const bool bn = (flags & 64) != 0;      // EPI_BNRED: requested through the BnRedArgs, as the engine does
+    rc = r3m::conv_dgrad_launch_br(nullptr, nullptr, nullptr, nullptr, nullptr, (flags & 4) ? some_bits : nullptr, N, H, W, Ci, Co, k, stride, pad,
+                                   flags & ~64, dtype, bn ? &br : nullptr, nullptr);
+  }
+  const int n = r3m::gg_route_record_end();
+  return rc ? -1 : n;
+}
 void r3m_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on.store(on != 0, std::memory_order_relaxed);

@@ -140,10 +140,13 @@ int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher wi
 // kernel: a block that finds its CU shared with another stream's kernel — RCCL during an overlapped all-reduce — simply takes
 // fewer tiles). Consumed (and cleared) by that launch whether or not it uses them; launches without it assign tiles statically.
 void gg_set_tile_counters(unsigned* ctr8, int sets = 1);
+void gg_route_record_begin(int* out, int cap);   // dry run on this thread: launch_gather_gemm records its kernel family and launches nothing
+int gg_route_record_end();                       // -> launches seen since begin
 bool wgrad_rowwin_eligible(const WgradParams& p);                       // wgrad_win.hip: 3x3 / stride 1 / pad 1, fp32, whole 64- or 128-wide tiles
 int launch_wgrad_rowwin(WgradParams& p, int splitK, hipStream_t s);
 int gg_set_dynamic_tiles(int on);        // diagnostic switch (r3m_debug_set_dynamic_tiles): 0 = ignore the counters, assign statically
-bool pw_gemm_eligible(const GatherGemmParams& p);          // conv_pw.hip: persistent kernel for 1x1 / stride-1 launches (fp32)
+bool pw_gemm_eligible(const GatherGemmParams& p);
+int pw_gemm_form(const GatherGemmParams& p);            // 0 none, 1 pointwise, 2 gather, 3 gather with strided output rows          // conv_pw.hip: persistent kernel for 1x1 / stride-1 launches (fp32)
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s);
 int launch_wgrad(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_pick_split(int M, int Co, int Ci, int T);

@@ -942,6 +942,30 @@ void gg_set_tile_counters(unsigned* ctr8, int sets) {
 }
 int gg_set_dynamic_tiles(int on) { const int old = g_dynamic_tiles; g_dynamic_tiles = on ? 1 : 0; return old; }
 
+// Which kernel family a launch runs (a pure function of the launch parameters; taps must be packed). Also what
+// r3m_debug_conv_route reports, so that the dispatch DESIGN.md describes is checked on CPU (tests/test_host.py).
+enum : int { GG_ROUTE_WIN = 1, GG_ROUTE_PW = 10 /* + pw_gemm_form: 11 pointwise, 12 gather, 13 strided output */, GG_ROUTE_K16 = 20,
+             GG_ROUTE_GLDS2 = 21, GG_ROUTE_OTHER = 22, GG_ROUTE_BF16 = 30 };
+static int gg_route(const GatherGemmParams& p) {
+  if (p.dtype == DT_BF16) return GG_ROUTE_BF16;
+  const bool glds2 = gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048;
+  if (gg_wide(p.Nc)) {
+    if (R3M_ENV_INT("R3M_GG_WIN", 1) && conv3x3_win_eligible(p, 28)) return GG_ROUTE_WIN;   // probe builds: 0 = gather kernel for 3x3 / stride 1 too
+    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) return GG_ROUTE_PW + pw_gemm_form(p);
+    // short main loop + wide output: single tap, K <= 256, N >= 2 K (expanding / downsample 1x1 convolutions) -> 16-wide K tiles
+    // R3M_GG_K16 (probe builds): 0 = never, 1 = the rule above, 2 = every wide launch (experiment: 4 blocks per CU everywhere)
+    const int k16_mode = R3M_ENV_INT("R3M_GG_K16", 1);
+    if ((p.Ci & 31) == 0 && (k16_mode == 2 || (k16_mode == 1 && p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci))) return GG_ROUTE_K16;
+    return glds2 ? GG_ROUTE_GLDS2 : GG_ROUTE_OTHER;
+  }
+  if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) return GG_ROUTE_PW + pw_gemm_form(p);
+  return glds2 ? GG_ROUTE_GLDS2 : GG_ROUTE_OTHER;
+}
+static thread_local int* t_route_out = nullptr;      // dry run (r3m_debug_conv_route): record the route of every launch, launch nothing
+static thread_local int t_route_n = 0, t_route_cap = 0;
+void gg_route_record_begin(int* out, int cap) { t_route_out = out; t_route_n = 0; t_route_cap = cap; }
+int gg_route_record_end() { const int n = t_route_n; t_route_out = nullptr; t_route_n = t_route_cap = 0; return n; }
+
 int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   GatherGemmParams p = p_in;
   p.tile_ctr = t_tile_ctr;     // one set of counters serves ONE launch: the parity-class launches of a stride-2 dgrad take the next
@@ -956,6 +980,11 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     R3M_REQUIRE(p.M > 0 && p.Nc > 0, "gather_gemm: empty problem M=%d Nc=%d", p.M, p.Nc);
     for (int t = 0; t < p.ntaps; ++t)
       p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
+    if (t_route_out) {
+      if (t_route_n < t_route_cap) t_route_out[t_route_n] = GG_ROUTE_BF16;
+      ++t_route_n;
+      return 0;
+    }
     return launch_gather_gemm_bf16(p, s);
   }
   R3M_REQUIRE(p.Ci % 32 == 0, "gather_gemm: Ci=%d must be a multiple of 32", p.Ci);
@@ -973,14 +1002,17 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
   const double kdim = (double)p.ntaps * p.Ci;
   const double flops = 2.0 * (double)p.M * (double)p.Nc * kdim;
+  const int route = gg_route(p);
+  if (t_route_out) {
+    if (t_route_n < t_route_cap) t_route_out[t_route_n] = route;
+    ++t_route_n;
+    return 0;
+  }
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    // short main loop + wide output: single tap, K <= 256, N >= 2 K (expanding / downsample 1x1 convolutions) -> 16-wide K tiles
-    // R3M_GG_K16 (probe builds): 0 = never, 1 = the rule above, 2 = every wide launch (experiment: 4 blocks per CU everywhere)
     {
-      const int winmode = R3M_ENV_INT("R3M_GG_WIN", 1);           // probe builds: 0 = gather kernel for 3x3 / stride 1 too
-      if (winmode && conv3x3_win_eligible(p, 28)) {
+      if (route == GG_ROUTE_WIN) {
         typedef WinCfg<128, 128, 192> Cfg;
 #define LAUNCH_WIN(E)                                                                                                        \
   do {                                                                                                                       \
@@ -995,19 +1027,17 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
         return check_launch("conv3x3_win");
       }
     }
-    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // dense output rows (1x1 / stride 1; any forward; stride-1 dgrads): persistent kernel (conv_pw.hip)
+    if (route > GG_ROUTE_PW && route < GG_ROUTE_K16) {   // dense or parity-strided output rows: persistent kernel (conv_pw.hip)
       if (int e = launch_pw_gemm(p, s)) return e;
       prof_bytes(gather_gemm_alg_bytes(p, 4));
       prof_end(s);
       return check_launch("pw_gemm");
     }
-    const int k16_mode = R3M_ENV_INT("R3M_GG_K16", 1);
-    const bool short_loop = (p.Ci & 31) == 0 && (k16_mode == 2 || (k16_mode == 1 && p.ntaps == 1 && p.Ci <= 256 && p.Nc >= 2 * p.Ci));
-    if (short_loop) {
+    if (route == GG_ROUTE_K16) {
 #define LAUNCH_K16(E) hipLaunchKernelGGL((gather_gemm_k16_kernel<E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_K16)
 #undef LAUNCH_K16
-    } else if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
+    } else if (route == GG_ROUTE_GLDS2) {
 #define LAUNCH_GLDS2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<128, 128, 2, 2, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_GLDS2)
 #undef LAUNCH_GLDS2
@@ -1025,13 +1055,13 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
   } else {
     const int grid = ceil_div(p.M, 256) * ceil_div(p.Nc, 64);
     prof_begin(KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
-    if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) {   // dense output rows, 64-wide output: persistent kernel, eight-wave 256 x 64 tile
+    if (route > GG_ROUTE_PW && route < GG_ROUTE_K16) {   // 64-wide output: persistent kernel, eight-wave 256 x 64 tile
       if (int e = launch_pw_gemm(p, s)) return e;
       prof_bytes(gather_gemm_alg_bytes(p, 4));
       prof_end(s);
       return check_launch("pw_gemm");
     }
-    if (gg_use_glds() == 2 && ((p.Ci >> 5) & 1) == 0 && p.Ci <= 2048) {
+    if (route == GG_ROUTE_GLDS2) {
 #define LAUNCH_NARROW2(E) hipLaunchKernelGGL((gather_gemm_glds2_kernel<256, 64, 4, 1, E>), dim3(grid), dim3(256), 0, s, p)
       GG_EPI_SWITCH(LAUNCH_NARROW2)
 #undef LAUNCH_NARROW2
