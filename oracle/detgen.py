@@ -106,3 +106,13 @@ def resnet_state_dict_no_kink(named_shapes, size, tag="nk", shift=4.0):
     last = ("layer4.2.bn3" if size == 50 else ("layer4.1.bn2" if size == 18 else "layer4.2.bn2")) + ".bias"
     out[last] = (out[last] + np.float32(shift)).astype(np.float32)
     return out
+
+
+# The kink-free golden cases (G8): (weight tag, last-BatchNorm bias shift, frames tag) per encoder size — three independent draws each
+# (tools/experiments/find_nokink.py found them: no float64 last-block pre-activation within 1e-3 of zero). State 0 is round 4's case.
+NOKINK_STATES = {
+    18: [("nk2", 4.0, "frames8nk"), ("nk6", 4.0, "frames8nke"), ("nk8", 4.0, "frames8nkg")],
+    34: [("nk2", 4.0, "frames8nk"), ("nk3", 4.0, "frames8nkb"), ("nk8", 4.0, "frames8nkg")],
+    50: [("nk2", 4.0, "frames8nk"), ("nk3", 4.0, "frames8nkb"), ("nk8", 4.0, "frames8nkg")],
+}
+NOKINK_SUFFIX = ["", "_b", "_c"]      # tests/golden/encoder_r{size}_nokink{suffix}.npz

@@ -8,7 +8,7 @@ OBJ="$HERE/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
-SRCS="conv conv_pw wgrad_win conv_bf16 stem_bf16 bn loss adam lang augment engine capi"
+SRCS="conv conv_pw wgrad_win conv_bf16 conv_pw16 stem_bf16 bn loss adam lang augment engine capi"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
   stale=0
@@ -17,7 +17,10 @@ for f in $SRCS; do
     [ "$dep" -nt "$OBJ/$f.o" ] && stale=1
   done
   if [ $stale = 1 ]; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    EXTRA=""
+    # conv_pw16: the tile tickets are requested one tile before they are used; the wave-level atomic optimizer would wait for each at once
+    [ "$f" = conv_pw16 ] && EXTRA="-mllvm -amdgpu-atomic-optimizer-strategy=None"
+    $HIPCC $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done

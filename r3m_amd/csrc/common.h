@@ -167,6 +167,10 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s);
 int launch_wgrad_bf16(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_bf16_pick_split(int M, int Co, int Ci, int T);
 int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s);
+// conv_pw16.hip: persistent warp-specialised kernel of the bf16 plans (dense / parity-strided output rows)
+int pw16_form(const GatherGemmParams& p);               // 0 none, 1 pointwise, 2 gather, 3 gather with strided output rows
+int launch_pw16(const GatherGemmParams& p, hipStream_t s);
+int pw16_set_mode(int mode);                            // diagnostic (r3m_debug_set_pw16): 0 = per-tile kernels everywhere; returns the old value
 int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s);
 
 // ---- launchers (stem_bf16.hip): the stem on the bf16 MFMA, from a padded bf16 image of the normalised frames ----

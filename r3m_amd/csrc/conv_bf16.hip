@@ -569,6 +569,14 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
     if (rc) return rc;
     return check_launch("conv3x3_halo_bf16");
   }
+  if (pw16_form(p)) {                          // dense / parity-strided output rows: the persistent warp-specialised kernel (conv_pw16.hip)
+    prof_begin(gg_wide(p.Nc) ? KC_GEMM_WIDE : KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    rc = launch_pw16(p, s);
+    prof_bytes(gather_gemm_alg_bytes(p, 2));
+    prof_end(s);
+    if (rc) return rc;
+    return check_launch("pw16_gemm");
+  }
   if (gg_wide(p.Nc)) {
     const int grid = ceil_div(p.M, 128) * ceil_div(p.Nc, 128);
     prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);

@@ -53,11 +53,18 @@ class _EncoderFn(torch.autograd.Function):
         h = module._run_forward(x, training, crop)
         ctx.module = module
         ctx.slot, ctx.generation = module._last_forward
+        module._awaiting += 1            # forwards whose backward has not run yet (max_live_forwards > 1: several per step)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        ctx.module._run_backward(dh.contiguous(), ctx.generation, ctx.slot)
+        m = ctx.module
+        m._awaiting = max(0, m._awaiting - 1)
+        # The data-parallel stage hook starts an ASYNC all-reduce on a slice of the flat gradient buffer. With several live forwards
+        # ((h1 + h2).backward()) every backward accumulates into the same buffer, so only the LAST outstanding one may fire it: an
+        # earlier one would hand RCCL a slice the next backward is still adding to. (A forward whose graph is dropped never
+        # decrements: the hook then never fires and finish_gradient_sync reduces the whole buffer itself.)
+        m._run_backward(dh.contiguous(), ctx.generation, ctx.slot, fire_hooks=m._awaiting == 0)
         return None, None, None, None, None
 
 
@@ -123,6 +130,7 @@ class HipResNet(nn.Module):
         self.fc = nn.Identity()   # models_r3m.py:62
         self._flat_p, self._flat_b, self._flat_nbt = flat_p, flat_b, flat_nbt
         self._flat_g = None
+        self._awaiting = 0      # forwards through autograd whose backward has not run yet (see _EncoderFn.backward)
         self._ring = [_LiveSlot() for _ in range(self.max_live_forwards)]   # _plans / _arena below are slot 0's
         self._ring_pos = 0
         self._last_forward = (0, 0)   # (slot, generation) of the most recent forward
@@ -293,7 +301,7 @@ class HipResNet(nn.Module):
         reference R3M deep-copies cleanly (plain nn.Module), so must this."""
         st = self.__dict__.copy()
         st.update(_ring=[_LiveSlot() for _ in self._ring], _ring_pos=0, _last_forward=(0, 0), _flat_g=None, _stage_hook=None,
-                  _grad_fresh=True)
+                  _grad_fresh=True, _awaiting=0)
         return st
 
     def __setstate__(self, st):
@@ -334,7 +342,7 @@ class HipResNet(nn.Module):
         self._last_forward = (si, slot.generation)
         return out
 
-    def _run_backward(self, dh, generation, si=0):
+    def _run_backward(self, dh, generation, si=0, fire_hooks=True):
         slot = self._ring[si]
         if generation != slot.generation or slot.arena is None:
             raise RuntimeError(f"r3m_amd: the encoder ran {len(self._ring)} other forward(s) before this backward; its saved "
@@ -348,7 +356,7 @@ class HipResNet(nn.Module):
             for stage in range(4):
                 _lib.check(L.r3m_resnet_backward(h, dh.data_ptr(), self._flat_p.data_ptr(), g.data_ptr(), slot.arena.data_ptr(), stage,
                                                  stage + 1, accumulate, _lib.stream_ptr(dh.device)), "resnet_backward")
-                if self._stage_hook is not None:
+                if self._stage_hook is not None and fire_hooks:
                     off, cnt = self.stage_range(stage)
                     self._stage_hook(stage, off, cnt)
         self._grad_fresh = False

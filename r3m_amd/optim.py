@@ -58,6 +58,19 @@ class FusedAdam(torch.optim.Optimizer):
                                            float(b1), float(b2), float(eps), self._steps[i], float(self.grad_scale),
                                            _lib.stream_ptr(p.device)), "adam_step")
 
+    def moments(self, param):
+        """Read-only views (exp_avg, exp_avg_sq) of Adam's moments for one parameter, shaped and strided like it — what
+        `torch.optim.Adam.state[param]` holds in the reference (models_r3m.py:76). None before the owner's first step."""
+        for i, o in enumerate(self.owners):
+            flat = o.flat_params()
+            off = (param.data_ptr() - flat.data_ptr()) // flat.element_size()
+            if param.device == flat.device and 0 <= off and off + param.numel() <= flat.numel():
+                if self._m[i] is None:
+                    return None
+                view = lambda t: torch.as_strided(t.detach(), param.shape, param.stride(), off)
+                return view(self._m[i]), view(self._v[i])
+        raise KeyError("FusedAdam.moments: the tensor is not a parameter of this optimizer's owners")
+
     @property
     def _step(self):
         """Step count of the first owner (the encoder): what the snapshot's `step` key has always meant."""

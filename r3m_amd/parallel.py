@@ -137,6 +137,8 @@ class DistributedR3M(nn.Module):
         self._head_done = False
         self.min_slice_bytes = int(min_slice_bytes)
         self._held = None   # (offset, count) of finished slices not sent yet (smaller than min_slice_bytes so far)
+        self._enc_sent = False   # the encoder's gradient slices of this step went out from the stage hooks
+        self._stages_seen = 0    # stage hooks fired since the last finish_gradient_sync()
         # identical replicas: rank 0's parameters and BatchNorm buffers win
         for owner in self._owners():
             self.sync.broadcast(owner.flat_params())
@@ -162,8 +164,15 @@ class DistributedR3M(nn.Module):
                 self.sync.reduce_slice(g, 0, g.numel())
 
     def _on_stage(self, stage, offset, count):
+        if self._enc_sent and stage == 0:
+            # a second encoder backward after the slices of this step went out: it would accumulate into buffers RCCL is reducing
+            # (and gloo would divide twice). The encoder fires the hooks for the LAST live backward only (max_live_forwards > 1), so
+            # this is a backward that came after one the encoder believed to be the last — e.g. two separate .backward() calls
+            raise RuntimeError("r3m_amd.DistributedR3M: a second encoder backward ran before finish_gradient_sync(); sum the losses "
+                               "and call backward() once per step (or call finish_gradient_sync() + the optimizer step in between)")
         if stage == 0:
             self._reduce_heads()
+        self._stages_seen += 1
         if self._held is not None:
             ho, hc = self._held
             if offset + count == ho:          # backward walks the flat buffer downwards: the new slice ends where the held one begins
@@ -173,6 +182,8 @@ class DistributedR3M(nn.Module):
             else:                             # not neighbours (never for the engine's stage order): send the held slice by itself
                 self.sync.reduce_slice(self.module.convnet.flat_grads(), ho, hc)
             self._held = None
+        if stage == self.LAST_STAGE:
+            self._enc_sent = True
         if stage < self.LAST_STAGE and count * 4 < self.min_slice_bytes:
             self._held = (offset, count)
             return
@@ -209,8 +220,17 @@ class DistributedR3M(nn.Module):
         head gradients now if no encoder backward ran, e.g. a frozen encoder)."""
         self._reduce_heads()
         self._flush_held()          # a backward that stopped before the last stage (partial stage range) leaves nothing behind
+        conv = self.module.convnet
+        if self._stages_seen == 0 and conv._flat_g is not None and not conv._grad_fresh:
+            # encoder gradients exist but no backward fired the stage hooks (several live forwards of which one was never
+            # backpropagated): reduce the whole buffer now — correct, just not overlapped
+            g = conv.flat_grads()
+            self.sync.reduce_slice(g, 0, g.numel())
+            conv._awaiting = 0
         self.sync.finish()
         self._head_done = False
+        self._enc_sent = False
+        self._stages_seen = 0
 
 
 def make_network_wrapper(model, force=False, global_negatives=False):

@@ -271,6 +271,57 @@ def test_full_step_matches_reference_golden(hip, golden_dir, size):
     assert int(sd["bn1.num_batches_tracked"]) == 2
 
 
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_two_steps_small_lr_match_reference_golden(hip, golden_dir, size):
+    """G9: the G5 case at lr = 1e-7 (tests/golden/make_golden.py::step_small_lr_golden, the reference's own Trainer.update +
+    torch.optim.Adam): no Adam sign chaos, so the TWO-step pipeline of every size — second forward on updated running statistics,
+    Adam's moments, num_batches_tracked — is gated at fp32 tolerances: metrics of both steps 2e-4, running statistics 1e-4, and
+    exp_avg / exp_avg_sq of conv1.weight and of the last BatchNorm's weight after each step (exp_avg after step 1 = 0.1 x the
+    gradient: gated against the reference at the tolerance the kink-free gradient test establishes for the same tensors)."""
+    from oracle import detgen
+    from r3m_amd import R3M
+    from r3m_amd.parallel import SingleDevice
+    from r3m_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, f"step_r{size}_lr1e-7.npz"))
+    lr = float(g["lr"])
+    m = R3M("cuda", lr, 1024, size=size, l2weight=1e-5, l1weight=1e-5, langweight=0.0, tcnweight=1.0)
+    _load_state(m.convnet)
+    model = SingleDevice(m).to(DEV)
+    frames = torch.from_numpy(detgen.frames("stepframes", (2, 5, 3, 224, 224))).to(DEV)
+    torch.manual_seed(77)
+    T = Trainer(1)
+    names = [str(n) for n in g["metric_names"]]
+    lb = _last_bn(size)
+    P = dict(m.convnet.named_parameters())
+    for s in range(2):
+        metrics, _ = T.update(model, (frames, [""] * 2), s)
+        torch.cuda.synchronize()
+        ref = dict(zip(names, g[f"metric_values_{s}"]))
+        report(f"r{size} lr=1e-7 step {s}: " + ", ".join(f"{k} {metrics[k]:.6g} (ref {ref[k]:.6g})" for k in names))
+        for k in names:
+            assert abs(metrics[k] - ref[k]) <= 2e-4 * max(1.0, abs(ref[k])), (s, k, metrics[k], ref[k])
+        for pname, key in (("conv1.weight", "conv1"), (lb + ".weight", "lastbn")):
+            mom = m.encoder_opt.moments(P[pname])
+            assert mom is not None
+            ea, eas = mom[0].cpu().numpy(), mom[1].cpu().numpy()
+            e1 = rel_err(ea, g[f"exp_avg_{key}_{s}"])
+            e2 = rel_err(eas, g[f"exp_avg_sq_{key}_{s}"])
+            report(f"r{size} lr=1e-7 step {s} Adam moments of {pname}: exp_avg max-rel {e1[0]:.3e} l2 {e1[1]:.3e}, exp_avg_sq max-rel {e2[0]:.3e} l2 {e2[1]:.3e}")
+            # the reference's own fp32 gradient of conv1 sits 3e-3 (ResNet-18) .. 2e-2 (ResNet-50) l2-rel from float64 (G8): two fp32
+            # evaluations agree to that, not to 1e-4; the last BatchNorm's gradient is exact to 1e-4
+            tol = (6e-2 if size == 50 else 3e-2) if key == "conv1" else 2e-3
+            assert e1[1] < tol and e2[1] < 2 * tol, (s, pname, e1, e2)
+    sd = m.convnet.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", lb + ".running_mean", lb + ".running_var"):
+        e = rel_err(sd[k].cpu().numpy(), g["post_" + k])[0]
+        report(f"r{size} lr=1e-7 after two steps {k}: max-rel {e:.3e}")
+        assert e < 1e-4, (k, e)
+    for k in ("bn1.weight", lb + ".weight", "conv1.weight"):
+        d = np.abs(sd[k].cpu().numpy() - g["post_" + k]).max()
+        assert d <= 2.1 * 2 * lr, (k, d)          # two steps of at most ~lr each, whatever the signs
+    assert int(sd["bn1.num_batches_tracked"]) == 2 == int(g["nbt"])
+
+
 def test_encoder_large_batch_properties(hip):
     """Full-size-ish properties that need no oracle: batch independence in eval mode, determinism, non-negativity."""
     from r3m_amd import R3M
@@ -410,27 +461,24 @@ def test_second_forward_before_backward(hip):
     (h2.sum() + h3.sum()).backward()
 
 
-@pytest.mark.parametrize("size", [18, 34, 50])
-def test_encoder_gradients_kink_free_case(hip, golden_dir, size):
-    """G8: the gradient gate with NO escape hatch. On the kink-free state (detgen.resnet_state_dict_no_kink:
-    no float64 pre-activation of the last block within 1.3e-3 of zero, tests/golden/encoder_r*_nokink.npz) every fp32 forward
-    makes the float64 ReLU decisions of the last block, so the HIP gradients are gated against float64 at <= 3x the error of the
-    reference's own PyTorch-CPU fp32 gradients of the same tensor (floor 1e-4) — unconditionally: no flip table, no re-evaluation
-    of the oracle with imposed decisions (that machinery stays a diagnostic on the G1/G2 case above)."""
+def _kink_free_draw(golden_dir, size, draw, fused_bn_reduce=None):
+    """One kink-free case (detgen.NOKINK_STATES[size][draw]): HIP gradients and the reference's own fp32 gradients against float64.
+    Returns {tensor name: (hip l2-rel error, reference error)} for the seven named tensors + "rms" / "worst" over ALL tensors."""
     from oracle import detgen
     from r3m_amd import R3M
-    g = np.load(os.path.join(golden_dir, f"encoder_r{size}_nokink.npz"))
+    tag, shift, frames = detgen.NOKINK_STATES[size][draw]
+    g = np.load(os.path.join(golden_dir, f"encoder_r{size}_nokink{detgen.NOKINK_SUFFIX[draw]}.npz"))
     assert float(g["min_abs_z"]) > 1e-3
     m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0).to(DEV)
     shapes = [(k, tuple(v.shape)) for k, v in m.convnet.state_dict().items()]
-    sd = detgen.resnet_state_dict_no_kink(shapes, size, tag="nk2", shift=4.0)
+    sd = detgen.resnet_state_dict_no_kink(shapes, size, tag=tag, shift=shift)
     m.convnet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     m.train()
-    x = torch.from_numpy(detgen.frames("frames8nk", (8, 3, 224, 224))).to(DEV)
+    x = torch.from_numpy(detgen.frames(frames, (8, 3, 224, 224))).to(DEV)
     h = m(x)
     e = rel_err(h.detach().cpu().numpy(), g["h_train"])[0]
     e64 = rel_err(h.detach().cpu().numpy(), g["h_train_fp64"])[0]
-    report(f"r{size} kink-free: train-mode embedding max-rel vs reference fp32 {e:.2e}, vs float64 {e64:.2e}")
+    report(f"r{size} kink-free draw {draw} ({tag}, {frames}): train-mode embedding max-rel vs reference fp32 {e:.2e}, vs float64 {e64:.2e}")
     assert e < 1e-4
     cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).to(DEV)
     (h * cw).sum().backward()
@@ -447,23 +495,43 @@ def test_encoder_gradients_kink_free_case(hip, golden_dir, size):
         sq_hip += e_hip * e_hip
         sq_cpu += e_cpu * e_cpu
     n_t = len(g["grad_names"])
-    rms_hip, rms_cpu = (sq_hip / n_t) ** 0.5, (sq_cpu / n_t) ** 0.5
-    report(f"r{size} kink-free: grad-norm rel vs fp64 over {n_t} tensors: worst hip {worst_hip:.3e} ({worst_name}) reference-cpu-fp32 {worst_cpu:.3e}; "
-           f"rms hip {rms_hip:.3e} reference-cpu-fp32 {rms_cpu:.3e}")
+    out = {"rms": ((sq_hip / n_t) ** 0.5, (sq_cpu / n_t) ** 0.5), "worst": (worst_hip, worst_cpu)}
+    report(f"r{size} kink-free draw {draw}: grad-norm rel vs fp64 over {n_t} tensors: worst hip {worst_hip:.3e} ({worst_name}) reference-cpu-fp32 "
+           f"{worst_cpu:.3e}; rms hip {out['rms'][0]:.3e} reference-cpu-fp32 {out['rms'][1]:.3e} ratio {out['rms'][0] / max(out['rms'][1], 1e-12):.2f}")
     lb = _last_bn(size)
-    fails = []
     for k in ("conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight"):
         hip_err = rel_err(P[k].grad.cpu().numpy(), g["grad64_" + k])[1]
         cpu_err = rel_err(g["grad_" + k], g["grad64_" + k])[1]
-        report(f"r{size} kink-free grad {k}: l2-rel vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}  ratio {hip_err / max(cpu_err, 1e-12):.2f}")
-        if hip_err > max(3.0 * cpu_err, 1e-4):
-            fails.append((k, hip_err, cpu_err))
+        out[k] = (hip_err, cpu_err)
+        report(f"r{size} kink-free draw {draw} grad {k}: l2-rel vs fp64: hip {hip_err:.3e}  reference-cpu-fp32 {cpu_err:.3e}  ratio {hip_err / max(cpu_err, 1e-12):.2f}")
+    return out
+
+
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_encoder_gradients_kink_free_case(hip, golden_dir, size):
+    """G8 (made statistical in round 5 — VERDICT r4 item 3): the gradient gate with NO escape hatch. On a kink-free
+    state (detgen.resnet_state_dict_no_kink: no float64 pre-activation of the last block within 1e-3 of zero) every fp32 forward
+    makes the float64 ReLU decisions of the last block, so the HIP gradients are gated against float64 relative to the error of the
+    reference's own PyTorch-CPU fp32 gradients of the same tensor — unconditionally: no flip table, no re-evaluation of the oracle.
+    ONE golden state is one draw of fp32 round-off on each side (round 4's ResNet-18 draw read 2.2-2.9 against a 3.0 gate), so the
+    gate runs over THREE independent (weights, frames) draws per size (detgen.NOKINK_STATES): the MEDIAN ratio hip / reference must be
+    <= 2 and every single draw <= 4 (an error below 1e-4 always passes), for the seven named tensors and for the rms over all
+    parameter tensors; the single worst tensor of a draw stays within 4x the reference's own worst."""
+    draws = [_kink_free_draw(golden_dir, size, d) for d in range(3)]
+    fails = []
+    for k in draws[0]:
+        if k == "worst":
+            continue
+        ratios = []
+        for d in draws:
+            hip_err, cpu_err = d[k]
+            ratios.append(0.0 if hip_err <= 1e-4 else hip_err / max(cpu_err, 1e-12))
+        med = sorted(ratios)[1]
+        report(f"r{size} kink-free {k}: hip / reference error ratios over the three draws {', '.join(f'{r:.2f}' for r in ratios)}  median {med:.2f}")
+        if med > 2.0 or max(ratios) > 4.0:
+            fails.append((k, ratios))
+    for i, d in enumerate(draws):
+        # the single worst tensor = the maximum of 60-159 strongly correlated draws (one perturbation reaches every tensor below it)
+        if d["worst"][0] > max(4.0 * d["worst"][1], 1e-4):
+            fails.append(("worst", i, d["worst"]))
     assert not fails, fails
-    # all tensors at once: the norm error of a SINGLE tensor is one draw of fp32 round-off carried through 18-50 BatchNorm backward
-    # passes (the reference's own worst value ranges over 5e-4 .. 4e-3 between the three networks; measured hip / reference ratios
-    # of the rms: ResNet-18 2.9, ResNet-34 0.6, ResNet-50 1.1), so the 3x gate is applied to the root-mean-square over all
-    # parameter tensors
-    assert rms_hip <= max(3.0 * rms_cpu, 1e-4), (rms_hip, rms_cpu)
-    # the single worst tensor = the maximum of 60-159 strongly correlated draws (one perturbation reaches every tensor below it):
-    # measured 3.9x the rms for this path and 3.5x for the reference on ResNet-18 — gated at 4x the reference's own worst
-    assert worst_hip <= max(4.0 * worst_cpu, 1e-4), (worst_hip, worst_name, worst_cpu)

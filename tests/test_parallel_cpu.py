@@ -110,6 +110,71 @@ def _worker(rank, world, port, q):
             m2.convnet._stage_hook(stage, *m2.convnet.stage_range(stage))
         net2.finish_gradient_sync()
         assert net2.sync.launched == before + 4
+        # ---- several live forwards per step (max_live_forwards = 2, `(h1 + h2).backward()`): every backward accumulates into the
+        # same flat buffer, so only the LAST outstanding one may start the asynchronous slice reductions. The native
+        # engine is replaced by a stand-in that fills the buffer the way it does (overwrite, then accumulate) and honours fire_hooks.
+        from r3m_amd.encoder import _EncoderFn
+        torch.manual_seed(300 + rank)
+        m3 = R3M("cpu", 1e-4, 64, size=18, langweight=0.0, tcnweight=1.0, max_live_forwards=2)
+        net3 = make_network_wrapper(m3)
+        conv = m3.convnet
+        fired = []
+
+        def fake_forward(x, training, crop=None):
+            conv._last_forward = (0, 0)
+            return torch.ones((x.shape[0], conv.outdim))
+
+        def fake_backward(dh, generation, si=0, fire_hooks=True):
+            gb = conv.flat_grads()
+            if conv._grad_fresh:
+                gb.zero_()
+            gb += float(rank + 1)
+            conv._grad_fresh = False
+            fired.append(fire_hooks)
+            if fire_hooks and conv._stage_hook is not None:
+                for stage in range(4):
+                    conv._stage_hook(stage, *conv.stage_range(stage))
+
+        conv._run_forward, conv._run_backward = fake_forward, fake_backward
+        anchor = next(conv.parameters())
+        x = torch.zeros((5, 3, 224, 224))
+        for step in range(2):
+            m3.encoder_opt.zero_grad()
+            h1 = _EncoderFn.apply(x, anchor, conv, True, None)
+            h2 = _EncoderFn.apply(x, anchor, conv, True, None)
+            assert conv._awaiting == 2
+            fired.clear()
+            before = net3.sync.launched
+            (h1.sum() + h2.sum()).backward()
+            assert fired == [False, True] and conv._awaiting == 0, fired      # the hooks fired once, for the last backward
+            net3.finish_gradient_sync()
+            assert net3.sync.launched == before + 2                           # ResNet-18: two slices, each sent ONCE
+            g3 = conv.flat_grads()
+            assert torch.allclose(g3, torch.full_like(g3, 2.0 * sum(range(1, world + 1)) / world)), float(g3[0])
+        # a forward whose graph is dropped keeps the count up: no backward fires the hooks, finish() reduces the whole buffer itself
+        m3.encoder_opt.zero_grad()
+        h1 = _EncoderFn.apply(x, anchor, conv, True, None)
+        h2 = _EncoderFn.apply(x, anchor, conv, True, None)
+        fired.clear()
+        before = net3.sync.launched
+        h2.sum().backward()
+        del h1
+        assert fired == [False]
+        net3.finish_gradient_sync()
+        assert net3.sync.launched == before + 1 and conv._awaiting == 0
+        g3 = conv.flat_grads()
+        assert torch.allclose(g3, torch.full_like(g3, sum(range(1, world + 1)) / world))
+        # two SEPARATE backward() calls in one step: the second would add into slices that are being reduced — refused
+        m3.encoder_opt.zero_grad()
+        h1 = _EncoderFn.apply(x, anchor, conv, True, None)
+        h1.sum().backward()
+        h2 = _EncoderFn.apply(x, anchor, conv, True, None)
+        try:
+            h2.sum().backward()
+            raise AssertionError("second encoder backward before finish_gradient_sync() was accepted")
+        except RuntimeError as e:
+            assert "second encoder backward" in str(e)
+        net3.finish_gradient_sync()
         # one-rank semantics of `force` are exercised on the GPU (tests/test_gpu_ddp.py); here: world 2 is active without it
         assert net2.sync.active
         # plain GradSync on an arbitrary buffer + no-op at count 0
