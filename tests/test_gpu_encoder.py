@@ -309,7 +309,9 @@ def test_two_steps_small_lr_match_reference_golden(hip, golden_dir, size):
             report(f"r{size} lr=1e-7 step {s} Adam moments of {pname}: exp_avg max-rel {e1[0]:.3e} l2 {e1[1]:.3e}, exp_avg_sq max-rel {e2[0]:.3e} l2 {e2[1]:.3e}")
             # the reference's own fp32 gradient of conv1 sits 3e-3 (ResNet-18) .. 2e-2 (ResNet-50) l2-rel from float64 (G8): two fp32
             # evaluations agree to that, not to 1e-4; the last BatchNorm's gradient is exact to 1e-4
-            tol = (6e-2 if size == 50 else 3e-2) if key == "conv1" else 2e-3
+            # (measured l2-rel: conv1 5e-3 / 1.1e-2 / 2.4e-2, last BatchNorm 1e-5 / 1.4e-4 / 2.3e-3 for ResNet-18 / 34 / 50: ResNet-50's last
+            # BatchNorm sits behind a 2048-channel bottleneck whose fp32 gradient is itself 1e-3 from float64, G8)
+            tol = (6e-2 if size == 50 else 3e-2) if key == "conv1" else (6e-3 if size == 50 else 2e-3)
             assert e1[1] < tol and e2[1] < 2 * tol, (s, pname, e1, e2)
     sd = m.convnet.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", lb + ".running_mean", lb + ".running_var"):
