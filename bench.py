@@ -381,6 +381,18 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
     return out
 
 
+def csrc_sha16():
+    """sha256 over r3m_amd/csrc/*.{hip,h} (sorted by name), first 16 hex digits: identifies the kernel sources of THIS tree (the GPU
+    box has no .git). tools/pmc_report.py stamps the PMC summaries with the same function."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "r3m_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "r3m_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(bf16, size, clips, dom_kernel):
     """HBM bytes per launch of the dominant class from the PMC passes (rocprofv3 --pmc cannot run inside this process): NOT
     measured in this run — read from the committed summary of the last counter run and labelled as such. The summary is only
@@ -404,8 +416,12 @@ def pmc_traffic(bf16, size, clips, dom_kernel):
     tag = (pj.get("dominant_kernel") or "").split()[0:2]          # e.g. ["gather_gemm", "128x128"]
     if not tag or "_".join(tag) not in dom_kernel.replace(" ", "_"):
         return None, f"profiles/{pmc_name} describes {pj.get('dominant_kernel')!r}, the dominant class here is {dom_kernel.split(' (')[0]!r}"
+    stamp = pj.get("csrc_sha16")
+    here = csrc_sha16()
+    build = ("collected on THIS build" if stamp == here else
+             f"collected on ANOTHER build (csrc {stamp or 'unstamped: before round 5'}, this tree {here}): re-run tools/gpu_pmc.sh")
     return pj.get("dominant_kernel_hbm_bytes_per_launch"), (
-        f"profiles/{pmc_name} <- {src} (separate rocprofv3 --pmc passes of an earlier run of this command; "
+        f"profiles/{pmc_name} <- {src} (separate rocprofv3 --pmc passes of an earlier run of this command, {build}; "
         f"FETCH_SIZE x2 + WRITE_SIZE, KiB units; not measured live)")
 
 
@@ -487,6 +503,21 @@ def main():
                 sec[name] = r
         if rank == 0:
             out["secondary"] = sec
+        # what the measurement aid costs: the timed steps above bracket every conv GEMM launch with HIP events (r3m_profile_enable);
+        # one short leg of the same workload without them, after everything else
+        if not args.no_kernel_timing:
+            try:
+                r0 = measure(w, min(args.steps, 10), 3, min(args.prewarm_seconds, 1.0), ctx, kernel_timing=False)
+            except Exception as e:
+                if use_dist:
+                    raise
+                r0 = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                if "error" in r0:
+                    out["kernel_timing_overhead_ms"] = None
+                else:
+                    out["ms_per_step_without_kernel_timing"] = r0["ms_per_step"]
+                    out["kernel_timing_overhead_ms"] = round(out["ms_per_step"] - r0["ms_per_step"], 3)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if affinity0 is not None:

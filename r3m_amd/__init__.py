@@ -50,7 +50,10 @@ def _default_config(size):
     return load_config(os.path.join(here, "cfgs", "config_rep.yaml"), [f"agent.size={size}", "agent.langweight=1.0"])
 
 
-def load_r3m(modelid):
+def load_r3m(modelid, replicate=False):
+    """The reference's loader (/root/reference/r3m/__init__.py:44-75), local cache only. Returns a wrapper exposing `.module` like
+    the reference's DataParallel: SingleDevice (the module on ONE GPU) by default; `replicate=True` returns
+    parallel.ReplicatedInference, which splits an inference batch over all visible GPUs as DataParallel does."""
     if modelid not in _MODEL_IDS:
         raise NameError('Invalid Model ID')
     foldername, size = _MODEL_IDS[modelid]
@@ -61,7 +64,11 @@ def load_r3m(modelid):
     modelcfg = load_config(configpath) if have_ckpt else _default_config(size)
     cleancfg = cleanup_config(modelcfg)
     rep = instantiate(cleancfg)
-    rep = SingleDevice(rep)       # exposes `.module` and `module.`-prefixed state-dict keys like DataParallel
+    if replicate:
+        from .parallel import ReplicatedInference
+        rep = ReplicatedInference(rep.to(device) if device != "cpu" else rep)
+    else:
+        rep = SingleDevice(rep)   # exposes `.module` and `module.`-prefixed state-dict keys like DataParallel
     if have_ckpt:
         sd = remove_language_head(torch.load(modelpath, map_location=torch.device(device))["r3m"])
         rep.load_state_dict(sd)

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, BM / WM > 64 ? 2 : 1) void conv3x3_halo_bf16_k
   const int halo_bytes = hri * 1024;
   unsigned char* zrow = smem + halo_bytes;                            // 128 zero bytes (1 KiB reserved)
   unsigned char* wring = zrow + 1024;
-  if (tid < 8) *reinterpret_cast<uint4*>(zrow + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < 16) *reinterpret_cast<uint4*>(zrow + tid * 16) = make_uint4(0u, 0u, 0u, 0u);   // 256 zero bytes: see the fragment addressing below
 
   const int srow = lane >> 3, pslot = lane & 7;
   const long long hb = (long long)m0 - (W + 1);                        // pixel staged in halo row 0
@@ -386,8 +386,12 @@ __global__ __launch_bounds__(256, BM / WM > 64 ? 2 : 1) void conv3x3_halo_bf16_k
       for (int t = 0; t < TM; ++t) {
         const bool ok = (vmask[t] >> k) & 1u;
         const int rv = crow[t] + shift;
-        abase[t] = ok ? rv * 128 : zoff;
-        akey[t] = ok ? ((rv >> 1) & 7) : 0;
+        // Round 5: a masked lane reads its zeros at the SAME position of the 256-byte bank window its real row would have used
+        // (row parity picks the 128-byte half, the swizzled slot the 16 bytes): the 16 lanes of a ds_read_b128 group then still hit
+        // 16 distinct positions. With ONE zero row at a fixed position a masked lane collided with whichever lane owned that slot:
+        // PMC showed 25 % of this kernel's LDS cycles as bank conflicts at 14 x 14 (profiles/r05_pw16_pmc_v5_halo.csv).
+        abase[t] = ok ? rv * 128 : zoff + (rv & 1) * 128;
+        akey[t] = (rv >> 1) & 7;
       }
       const unsigned char* fb = fragB0 + stage * WSTAGE;
 #pragma unroll

@@ -123,6 +123,61 @@ class SingleDevice(nn.Module):
         pass
 
 
+class ReplicatedInference(nn.Module):
+    """Opt-in multi-GPU INFERENCE for `load_r3m` users: the reference returns `DataParallel(rep)`, which splits an inference batch
+    over all visible GPUs and gathers the embeddings on GPU 0 (/root/reference/r3m/__init__.py:72). Here: one replica of the module
+    per device (deep copies, refreshed whenever the wrapped module's parameters or buffers change), the batch split along dim 0 in
+    device order, every chunk enqueued on its own device's stream (the chunks run concurrently), outputs concatenated on the first
+    device. `.module` and the state-dict key set are those of SingleDevice. Forward only: training is DistributedR3M's job (one
+    process per GPU) and a backward through this wrapper raises.
+    `devices` may name one device several times (tests on a one-GPU box exercise the split / gather logic that way)."""
+
+    def __init__(self, module, devices=None):
+        super().__init__()
+        self.module = module
+        if devices is None:
+            devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        self.devices = [torch.device(d) for d in devices]
+        if not self.devices:
+            raise RuntimeError("ReplicatedInference: no GPU visible")
+        self._replicas = None      # plain list on purpose: replicas are not sub-modules (not in state_dict(), not moved by .to())
+        self._stamp = None
+
+    def _state_stamp(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.module.parameters()) + list(self.module.buffers()))
+
+    def _ensure_replicas(self):
+        stamp = self._state_stamp()
+        if self._replicas is not None and stamp == self._stamp:
+            return
+        import copy
+        first = next(self.module.parameters()).device
+        self._replicas = []
+        for i, d in enumerate(self.devices):
+            if i == 0 and d == first:
+                self._replicas.append(self.module)
+            else:
+                self._replicas.append(copy.deepcopy(self.module).to(d).train(self.module.training))
+        self._stamp = stamp
+
+    def finish_gradient_sync(self):
+        pass
+
+    def forward(self, x, *a, **k):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.module.parameters()):
+            raise RuntimeError("ReplicatedInference is forward-only: wrap the call in torch.no_grad(); multi-GPU training is "
+                               "DistributedR3M (one process per GPU, python -m torch.distributed.run)")
+        self._ensure_replicas()
+        chunks = [c for c in torch.chunk(x, len(self.devices), dim=0) if c.shape[0] > 0]
+        outs = []
+        for rep, dev, c in zip(self._replicas, self.devices, chunks):
+            rep.train(self.module.training)
+            with torch.cuda.device(dev):
+                outs.append(rep(c.to(dev, non_blocking=True), *a, **k))
+        first = self.devices[0]
+        return torch.cat([o.to(first, non_blocking=True) for o in outs], 0)
+
+
 class DistributedR3M(nn.Module):
     """One replica per rank. Construct AFTER torch.distributed.init_process_group and after moving `module` to its GPU."""
 

@@ -563,3 +563,35 @@ def test_global_negatives_two_ranks_on_one_gpu(hip):
 def test_global_negatives_rccl(hip):
     _need_gpus(2)
     _check_gneg(_run_ranks(_gneg_worker, 2, "nccl"))
+
+
+DEV = "cuda:0"
+
+
+def test_replicated_inference_split_gather(hip):
+    """`load_r3m(..., replicate=True)` -> parallel.ReplicatedInference: what the reference's DataParallel wrapper does for an inference
+    batch (/root/reference/r3m/__init__.py:72) — split over the devices, one replica each, embeddings gathered on the first. One GPU
+    here, so it is named three times: 7 frames go out as chunks of 3 + 3 + 1 through three replicas."""
+    from r3m_amd import R3M
+    from r3m_amd.parallel import ReplicatedInference, SingleDevice
+    torch.manual_seed(3)
+    m = R3M("cuda", 1e-4, 1024, size=18, langweight=0.0, tcnweight=1.0).to(DEV).eval()
+    x = torch.randint(0, 256, (7, 3, 224, 224), device=DEV).float()
+    rep = ReplicatedInference(m, devices=[DEV, DEV, DEV])
+    with torch.no_grad():
+        ref = SingleDevice(m)(x)
+        out = rep(x)
+    assert out.shape == ref.shape and out.device == ref.device
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=1e-6)      # eval-mode frames are independent (chunk sizes pick other plans)
+    assert len(rep._replicas) == 3 and rep._replicas[0] is m and rep._replicas[1] is not m
+    assert list(rep.state_dict().keys()) == list(SingleDevice(m).state_dict().keys())      # replicas are not sub-modules
+    with torch.no_grad():
+        m.convnet.conv1.weight.mul_(0.5)                             # new weights: the replicas must follow
+        ref2 = SingleDevice(m)(x)
+        out2 = rep(x)
+    assert not torch.allclose(ref2, ref)
+    torch.testing.assert_close(out2, ref2, rtol=2e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        rep(x)                                                       # grad mode: training goes through DistributedR3M
+    with torch.no_grad():                                            # fewer frames than devices: empty chunks are skipped
+        torch.testing.assert_close(rep(x[:2]), SingleDevice(m)(x[:2]), rtol=2e-5, atol=1e-6)

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from r3m_amd import _lib
 
 L = _lib.lib()
+if os.environ.get("PW16_MODE") and hasattr(L, "r3m_debug_set_pw16"):
+    L.r3m_debug_set_pw16(int(os.environ["PW16_MODE"]))     # 0 per-tile kernels, 1 persistent pointwise / gather, 3 + window form
 mode = sys.argv[1]
 bf16 = mode.endswith("16")
 if bf16:

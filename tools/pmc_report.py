@@ -7,9 +7,24 @@ usage: pmc_report.py <dir with pmc_pass*.csv> <out_prefix> [pass-file suffix] [j
 (the last two = the workload the passes ran, default 50 / 256 = tools/gpu_pmc.sh's; bench.py refuses a summary of another workload)"""
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def csrc_sha16():
+    """The build these counters were collected on: sha256 over r3m_amd/csrc/*.{hip,h} (sorted by name), first 16 hex digits — the
+    same function as bench.py's, which says in its line whether `roofline.traffic` comes from the build it is timing."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "r3m_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "r3m_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 
 def short_name(k):
     """kernel-trace names of kernels with bf16 arguments come back mangled (the tracer's demangler does not know DF16b): keep
@@ -61,6 +76,9 @@ def group(k):
     k = re.sub(r"conv3x3_win_kernel<128, 128, 2, 2, \d+, \d+>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"conv3x3_halo_bf16_kernel<(128|256), 128, 2, 2, \d+>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"conv3x3_halo_bf16_kernel<256, 64, 4, 1, \d+>", "gather_gemm 256x64 (all epilogues)", k)
+    # round 5: the persistent big-tile bf16 kernel (conv_pw16.hip): wide outputs / 64-channel outputs
+    k = re.sub(r"pw16_gemm_kernel<256, (128|256), \d+, \d+(, \d+)*>", "gather_gemm 128x128 (all epilogues)", k)
+    k = re.sub(r"pw16_gemm_kernel<(256|512), 64, \d+, \d+(, \d+)*>", "gather_gemm 256x64 (all epilogues)", k)
     return k
 
 
@@ -104,7 +122,8 @@ with open(outp + ".csv", "w") as f:
 dom = rows[0]
 json.dump({"source": outp + ".csv", "workload": {"size": wl_size, "clips": wl_clips}, "dominant_kernel": dom["kernel"],
            "dominant_kernel_hbm_bytes_per_launch": int((dom["hbm_read_MB_per_launch"] + dom["hbm_write_MB_per_launch"]) * 1e6),
-           "dominant_kernel_mfma_util": dom["mfma_util"], "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units"},
+           "dominant_kernel_mfma_util": dom["mfma_util"], "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units",
+           "csrc_sha16": csrc_sha16()},
           open("profiles/" + json_name, "w"), indent=1)
 for r in rows[:16]:
     print(r)
