@@ -34,8 +34,9 @@ int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm1
 int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_t stream);
 /* Diagnostic: 0 = the encoder's persistent-kernel launches assign tiles statically, 1 (default) = per-XCD tile queues. Returns the old value. */
 int r3m_debug_set_dynamic_tiles(int on);
-/* Diagnostic (same-process A/B): 0 = the bf16 plans' forward / dgrad launches all run the per-tile kernels of csrc/conv_bf16.hip,
-   1 (default) = eligible launches run the persistent warp-specialised kernel of csrc/conv_pw16.hip. Returns the old value. */
+/* Diagnostic (same-process A/B): 0 (default) = the bf16 plans' forward / dgrad launches all run the per-tile kernels of
+   csrc/conv_bf16.hip; 1 = eligible launches run the persistent big-tile kernel of csrc/conv_pw16.hip (pointwise + gather forms),
+   3 = + its 3x3 window form. Bit-identical results; measured not faster inside the step. Returns the old value. */
 int r3m_debug_set_pw16(int mode);
 /* Diagnostic, runs without a GPU: which kernel family the gather-GEMM dispatch (csrc/conv.hip gg_route) picks for every launch of one
    convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual

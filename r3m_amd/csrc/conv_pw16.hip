@@ -582,7 +582,11 @@ __global__ __launch_bounds__(768, 3) void pw16_gemm_kernel(const GatherGemmParam
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------
-static int g_pw16_mode = 1;              // diagnostic switch (r3m_debug_set_pw16): 0 = the per-tile kernels of conv_bf16.hip everywhere
+// OFF by default (round 5): bit-identical to the per-tile kernels and 10-25 % faster on some 1x1 launches in isolation, but every
+// build of this file measured the STEP slower or neutral (configs[2] 90.1 -> 92.0 ms, configs[4] neutral; per-shape launches inside
+// the step: profiles/r05_pw16_instep_v5.txt, r05_side_stream_ab.txt). r3m_debug_set_pw16 / R3M_PW16 (probe builds) switch it in:
+// 1 = pointwise + gather forms, 3 = + the 3x3 window form; tests/test_gpu_pw16.py keeps it bit-identical while it is off.
+static int g_pw16_mode = R3M_ENV_INT("R3M_PW16", 0);
 int pw16_set_mode(int on) { const int old = g_pw16_mode; g_pw16_mode = on; return old; }
 
 static int p16_cu_count() {

@@ -391,8 +391,13 @@ static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float
   float* partial = c.arena + P.partial_off;
   double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
   gg_set_tile_counters(reinterpret_cast<unsigned*>(c.arena + P.ctr_off) + (&L - P.convs.data()) * 8);
-  TRY(conv_forward_launch(X, W, Y, partial, nullptr, N_eff, Hi_eff, Wi_eff, Ci_eff, L.Co, k_eff, stride_eff, pad_eff,
-                          c.training ? EPI_STATS : 0, c.dt, c.s));
+  {
+    // the counters are handed to "the next launch of this thread": if the launcher returns before it reaches launch_gather_gemm
+    // (a failed requirement), nothing later on this thread may inherit them
+    struct DropCounters { ~DropCounters() { gg_set_tile_counters(nullptr, 0); } } drop;
+    TRY(conv_forward_launch(X, W, Y, partial, nullptr, N_eff, Hi_eff, Wi_eff, Ci_eff, L.Co, k_eff, stride_eff, pad_eff,
+                            c.training ? EPI_STATS : 0, c.dt, c.s));
+  }
   const float* gamma = c.params + L.gamma_off;
   const float* beta = c.params + L.beta_off;
   if (c.training) {
@@ -568,7 +573,10 @@ static int side_init(Plan& P) {
     // Opt-in. Measured on ResNet-50 F=1280 (profiles/r01 notes in DESIGN.md): co-running wgrad with the BatchNorm-backward
     // passes lengthens the wgrad launches by about the BatchNorm time (the two do not overlap usefully on gfx950 even
     // though one is HBM-bound and the other MFMA-bound) -> step time unchanged (364.9 vs 364.5 ms). Kept for experiments.
-    P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0) != 0;
+    // 2 (round 5 experiment): wgrad(L) starts TOGETHER with dgrad(L) (both wait for dY_L only) and nothing on the main stream waits
+    // for it before its dY buffer is rewritten: the two GEMMs fill each other's tile-quantisation tails (every launch of the
+    // 1280-frame step has 490 k tiles for 512 slots).
+    P.use_side = R3M_ENV_INT("R3M_SIDE_STREAM", 0);
   }
   if (!P.bnred_init) {
     P.bnred_init = true;
@@ -637,10 +645,20 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   int* role = P.roles;
   auto Gp = [&](int r) { return arena + P.G_off[role[r]]; };
 
-  // call right AFTER dgrad(L) was enqueued on the main stream: wgrad(L) starts on the side stream once that dgrad is done
+  const bool side_co = side_on && P.use_side == 2;   // wgrad(L) runs beside dgrad(L)
+  // mode 2: call right BEFORE dgrad(L) is enqueued — the side stream may start wgrad(L) as soon as dY_L is complete
+  auto mark_dy = [&]() -> int {
+    if (!side_co) return 0;
+    if (hipEventRecord(P.ev_dy, s) != hipSuccess || hipStreamWaitEvent(P.side, P.ev_dy, 0) != hipSuccess) {
+      set_last_error("side stream: event ordering failed");
+      return 1;
+    }
+    return 0;
+  };
+  // call right AFTER dgrad(L) was enqueued on the main stream: wgrad(L) starts on the side stream once that dgrad is done (mode 1)
   auto wgrad_async = [&](const ConvSpec& L, const float* X, const float* dY, int ai) -> int {
     if (!side_on) return wgrad(c, L, X, dY);
-    if (hipEventRecord(P.ev_dy, s) != hipSuccess || hipStreamWaitEvent(P.side, P.ev_dy, 0) != hipSuccess) {
+    if (!side_co && (hipEventRecord(P.ev_dy, s) != hipSuccess || hipStreamWaitEvent(P.side, P.ev_dy, 0) != hipSuccess)) {
       set_last_error("side stream: event ordering failed");
       return 1;
     }
@@ -659,6 +677,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   };
   // before an MFMA-bound kernel goes to the main stream: every wgrad in flight must have finished
   auto wait_wgrads = [&]() -> int {
+    if (side_co) return mark_dy();      // mode 2: no wait; the dY just written is what the side stream waits for
     TRY(acquire_A(0));
     return acquire_A(1);
   };

@@ -15,6 +15,7 @@ There is no CPU or eager fallback: forward() on a non-CUDA tensor raises.
 import ctypes as C
 import math
 
+import weakref
 import torch
 import torch.nn as nn
 
@@ -50,10 +51,14 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, module, training, crop=None):
-        h = module._run_forward(x, training, crop)
+        h = module._run_forward(x, training, crop, saved=True)
         ctx.module = module
         ctx.slot, ctx.generation = module._last_forward
         module._awaiting += 1            # forwards whose backward has not run yet (max_live_forwards > 1: several per step)
+        if 0 <= ctx.slot < len(module._ring):
+            # the slot stays "live" while this graph node exists and has not run its backward: forwards that need no backward
+            # (no_grad / eval calls between a training forward and its backward) must not take it (_pick_slot)
+            module._ring[ctx.slot].waiting = weakref.ref(ctx)
         return h
 
     @staticmethod
@@ -65,6 +70,10 @@ class _EncoderFn(torch.autograd.Function):
         # earlier one would hand RCCL a slice the next backward is still adding to. (A forward whose graph is dropped never
         # decrements: the hook then never fires and finish_gradient_sync reduces the whole buffer itself.)
         m._run_backward(dh.contiguous(), ctx.generation, ctx.slot, fire_hooks=m._awaiting == 0)
+        if 0 <= ctx.slot < len(m._ring):
+            w = m._ring[ctx.slot].waiting
+            if w is not None and w() is ctx:
+                m._ring[ctx.slot].waiting = None
         return None, None, None, None, None
 
 
@@ -74,10 +83,35 @@ PRECISIONS = {"fp32": 0, "bf16": 1}   # R3M_DT_F32 / R3M_DT_BF16 (include/r3m_hi
 class _LiveSlot:
     """Saved state of one forward pass: native plans (per frame count; a plan also carries the staged-backward state), the HBM
     arena holding that forward's activations, and a generation counter that tells a late backward its activations are gone."""
-    __slots__ = ("plans", "arena", "generation", "F")
+    __slots__ = ("plans", "arena", "generation", "F", "waiting")
 
     def __init__(self):
         self.plans, self.arena, self.generation, self.F = {}, None, 0, None
+        self.waiting = None      # weakref to the autograd node whose backward will read this slot's activations (None: nobody)
+
+    @property
+    def live(self):
+        return self.waiting is not None and self.waiting() is not None
+
+
+def _pick_slot(live, pos, saved):
+    """Which slot the next forward writes its activations to. live[i]: slot i holds a forward whose backward is still to come;
+    pos: round-robin cursor; saved: this forward goes through autograd (a backward will read it). Returns (slot, new cursor);
+    slot -1 = the scratch slot (forwards nobody differentiates, when every ring slot is live).
+      * a free slot is always preferred (cursor order), so an inference call between a training forward and its backward never
+        evicts the training forward;
+      * a SAVED forward with every slot live evicts the oldest (the cursor): the evicted forward's backward raises and names the
+        remedy (max_live_forwards) — unchanged behaviour;
+      * an UNSAVED forward with every slot live runs in the scratch slot (its arena is allocated on first use and kept;
+        HipResNet.release_scratch() hands the HBM back)."""
+    k = len(live)
+    order = [(pos + i) % k for i in range(k)]
+    for i in order:
+        if not live[i]:
+            return i, ((i + 1) % k if saved else pos)
+    if saved:
+        return order[0], (order[0] + 1) % k
+    return -1, pos
 
 
 class HipResNet(nn.Module):
@@ -133,6 +167,7 @@ class HipResNet(nn.Module):
         self._awaiting = 0      # forwards through autograd whose backward has not run yet (see _EncoderFn.backward)
         self._ring = [_LiveSlot() for _ in range(self.max_live_forwards)]   # _plans / _arena below are slot 0's
         self._ring_pos = 0
+        self._scratch = None          # _LiveSlot for forwards without a backward while every ring slot is live (_pick_slot)
         self._last_forward = (0, 0)   # (slot, generation) of the most recent forward
         self._grad_fresh = True
         self._stage_hook = None   # callable(stage, offset, count) after each backward stage (data-parallel wrapper)
@@ -155,6 +190,8 @@ class HipResNet(nn.Module):
         if v is None:
             for sl in self._ring:
                 sl.arena = None
+            if self._scratch is not None:
+                self._scratch.arena = None
         else:
             self._ring[0].arena = v
 
@@ -276,8 +313,20 @@ class HipResNet(nn.Module):
         return off.value, cnt.value
 
     # ---- execution -------------------------------------------------------------------------------------------
+    def _slot(self, si):
+        if si >= 0:
+            return self._ring[si]
+        if self._scratch is None:
+            self._scratch = _LiveSlot()
+        return self._scratch
+
+    def release_scratch(self):
+        """Drop the scratch arena (HBM held by no_grad forwards that ran while every saved forward was still awaiting its backward)."""
+        if self._scratch is not None:
+            self._scratch.arena = None
+
     def _plan(self, F, slot=0):
-        plans = self._ring[slot].plans
+        plans = self._slot(slot).plans
         h = plans.get(F)
         if h is None:
             h = _lib.lib().r3m_resnet_create_dt(self.size, F, PRECISIONS[self.precision])
@@ -289,7 +338,7 @@ class HipResNet(nn.Module):
     def __del__(self):
         try:
             L = _lib.lib()
-            for sl in self._ring:
+            for sl in self._ring + ([self._scratch] if self._scratch is not None else []):
                 for h in sl.plans.values():
                     L.r3m_resnet_destroy(h)
         except Exception:
@@ -300,8 +349,8 @@ class HipResNet(nn.Module):
         hook belong to THIS object (a copied integer handle would be destroyed twice); the copy re-creates them lazily. The
         reference R3M deep-copies cleanly (plain nn.Module), so must this."""
         st = self.__dict__.copy()
-        st.update(_ring=[_LiveSlot() for _ in self._ring], _ring_pos=0, _last_forward=(0, 0), _flat_g=None, _stage_hook=None,
-                  _grad_fresh=True, _awaiting=0)
+        st.update(_ring=[_LiveSlot() for _ in self._ring], _ring_pos=0, _scratch=None, _last_forward=(0, 0), _flat_g=None,
+                  _stage_hook=None, _grad_fresh=True, _awaiting=0)
         return st
 
     def __setstate__(self, st):
@@ -309,14 +358,15 @@ class HipResNet(nn.Module):
         for p in self.parameters():      # gradients were views of the dropped flat buffer
             p.grad = None
 
-    def _run_forward(self, x, training, crop=None):
-        """x: [F,3,224,224] fp32 frames, or None with crop = augment.CroppedClips (raw clips + boxes, resampled in the stem pre-pass)."""
+    def _run_forward(self, x, training, crop=None, saved=False):
+        """x: [F,3,224,224] fp32 frames, or None with crop = augment.CroppedClips (raw clips + boxes, resampled in the stem pre-pass).
+        saved: the call comes from autograd (_EncoderFn) and a backward will read this forward's activations."""
         L = _lib.lib()
         src = crop.raw if crop is not None else x
         F = src.shape[0]
-        si = self._ring_pos                              # forwards take the slots round-robin: the oldest saved forward goes
-        self._ring_pos = (si + 1) % len(self._ring)
-        slot = self._ring[si]
+        si, self._ring_pos = _pick_slot([sl.live for sl in self._ring], self._ring_pos, saved)
+        slot = self._slot(si)
+        slot.waiting = None                              # whatever forward was saved here is gone now
         h = self._plan(F, si)
         need = L.r3m_resnet_arena_bytes(h)
         if slot.arena is None or slot.arena.numel() < need or slot.arena.device != src.device:
@@ -343,7 +393,7 @@ class HipResNet(nn.Module):
         return out
 
     def _run_backward(self, dh, generation, si=0, fire_hooks=True):
-        slot = self._ring[si]
+        slot = self._slot(si)
         if generation != slot.generation or slot.arena is None:
             raise RuntimeError(f"r3m_amd: the encoder ran {len(self._ring)} other forward(s) before this backward; its saved "
                                f"activations (one HBM arena per live forward) were overwritten. Construct the encoder with "

@@ -144,11 +144,16 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if bool(cfg.get("bind_cpus", True)):
+            # each rank's threads on cores of its GPU's NUMA node, disjoint from the other ranks' (utils/affinity.py). BEFORE the
+            # process group exists (RCCL's proxy / watchdog threads inherit the mask; existing threads would keep the old one) and
+            # before the loader workers fork. The rank takes its whole share of the node (launcher, autograd thread and
+            # `num_workers` loader processes live there); on a host too small for that the mask is left alone.
+            from .utils import affinity
+            info = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), max_cpus=None,
+                                      min_cpus=int(cfg.get("num_workers", 0)) + 2)
+            print(f"[local rank {local_rank}] host binding: {info}", flush=True)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # each rank's launcher thread on cores of its GPU's NUMA node, disjoint from the other ranks' (utils/affinity.py)
-        from .utils import affinity
-        info = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
-        print(f"[rank {dist.get_rank()}] host binding: {info}", flush=True)
     root_dir = Path.cwd() / "r3moutput" / str(cfg.experiment)
     root_dir.mkdir(parents=True, exist_ok=True)
     ws = Workspace(cfg, root_dir)

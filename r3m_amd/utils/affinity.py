@@ -78,17 +78,26 @@ def numa_cpus():
     return out
 
 
-def bind_rank(local_rank, local_world, device_indices=None, max_cpus=16, set_threads=True):
-    """Pin this process (all its current threads' future children inherit the mask) and cap torch's intra-op pool.
+def bind_rank(local_rank, local_world, device_indices=None, max_cpus=16, set_threads=True, min_cpus=1):
+    """Pin the CALLING thread — and every thread / process created from it afterwards, which inherit its mask — and cap torch's
+    intra-op pool. sched_setaffinity(0, ...) does not move threads that already exist: call this BEFORE init_process_group (RCCL's
+    proxy / watchdog threads) and before the loader workers are forked, or those keep the old mask.
+    max_cpus: upper bound of the slice (None: the rank's whole share of its NUMA node — a training run with loader workers);
+    min_cpus: what the caller needs at least (launcher + autograd thread + its loader workers); a smaller slice (a cgroup-limited
+    host: 32 CPUs over 8 ranks) would squeeze the workers next to the launcher — exactly the slowdown the binding is meant to
+    avoid — so the mask is then left alone and the returned dict says so.
     Returns a dict describing what was done — bench.py prints it per rank. Never raises: placement is an optimisation."""
     info = {"local_rank": local_rank, "numa_node": None, "cpus": None, "threads": None}
     try:
         allowed = sorted(os.sched_getaffinity(0))
         devs = list(device_indices) if device_indices is not None else list(range(local_world))
         nodes = [gpu_numa_node(d) for d in devs]
-        cpus = plan_rank_cpus(local_rank, nodes, numa_cpus(), allowed, max_cpus=max_cpus)
-        os.sched_setaffinity(0, cpus)
+        cpus = plan_rank_cpus(local_rank, nodes, numa_cpus(), allowed, max_cpus=max_cpus if max_cpus else len(allowed))
         info["numa_node"] = nodes[local_rank] if local_rank < len(nodes) else None
+        if len(cpus) < min_cpus:
+            info["skipped"] = f"slice of {len(cpus)} cpu(s) < {min_cpus} needed: affinity left as it was"
+            return info
+        os.sched_setaffinity(0, cpus)
         info["cpus"] = f"{cpus[0]}-{cpus[-1]}" if cpus == list(range(cpus[0], cpus[-1] + 1)) else ",".join(map(str, cpus))
         if set_threads:
             import torch

@@ -140,3 +140,6 @@ def test_bind_rank_never_raises_and_keeps_a_nonempty_mask():
             assert set(os.sched_getaffinity(0)) <= set(before) and info["cpus"]
     finally:
         os.sched_setaffinity(0, before)
+    # a slice smaller than what the caller needs (launcher + loader workers) leaves the mask alone and says so
+    info = affinity.bind_rank(0, 2, device_indices=[0, 1], set_threads=False, min_cpus=10 ** 6)
+    assert ("skipped" in info or "error" in info) and os.sched_getaffinity(0) == before

@@ -265,9 +265,10 @@ def test_full_step_matches_reference_golden(hip, golden_dir, size):
     # running statistics after TWO steps: 0.9 x (step-1 statistics, gated at 1e-4 by the encoder golden) + 0.1 x the statistics of
     # conv1 outputs under weights that already took one Adam step — and that step moves a weight by +-lr according to the SIGN of
     # its gradient (see above), so a few conv1 weights differ by 2 lr = 2e-4 from the reference's: 1e-4-level differences in the
-    # second batch mean are the optimizer's chaos, not arithmetic (measured: ResNet-18 < 1e-4, ResNet-34 1.1e-4)
+    # second batch mean are the optimizer's chaos, not arithmetic (measured: ResNet-18 < 1e-4, ResNet-34 1.1e-4). ResNet-18 keeps
+    # the 1e-4 gate it has always met; the chaos-free statement for all three sizes is the lr = 1e-7 golden below.
     for k in ("bn1.running_mean", "bn1.running_var"):
-        assert rel_err(sd[k].cpu().numpy(), g["post_" + k])[0] < 5e-4, k
+        assert rel_err(sd[k].cpu().numpy(), g["post_" + k])[0] < (1e-4 if size == 18 else 5e-4), k
     assert int(sd["bn1.num_batches_tracked"]) == 2
 
 
@@ -461,6 +462,22 @@ def test_second_forward_before_backward(hip):
     with pytest.raises(RuntimeError, match="max_live_forwards"):
         h1.sum().backward()
     (h2.sum() + h3.sum()).backward()
+    # a forward NOBODY differentiates (no_grad / inference call) between a training forward and its backward must not evict it
+    # (ADVICE r4): it takes a free slot, or the scratch slot when every ring slot is live
+    m1.encoder_opt.zero_grad()
+    h1 = m1.convnet(x1)
+    with torch.no_grad():
+        e2 = m1.convnet(x2)
+        e2b = m1.convnet(x2)
+    assert m1.convnet._scratch is not None and m1.convnet._scratch.arena is not None
+    (h1 * 0.5).sum().backward()
+    assert torch.equal(m1.convnet.flat_grads(), g_a)
+    assert torch.equal(e2, e2b)
+    m1.convnet.release_scratch()
+    assert m1.convnet._scratch.arena is None
+    with torch.no_grad():                                  # nothing is live any more: the ring slot itself serves, no scratch arena
+        e2c = m1.convnet(x2)
+    assert m1.convnet._scratch.arena is None and torch.equal(e2, e2c)
 
 
 def _kink_free_draw(golden_dir, size, draw, fused_bn_reduce=None):

@@ -1,0 +1,66 @@
+"""-m gpu: the persistent big-tile bf16 GEMM (csrc/conv_pw16.hip) against the per-tile kernels of csrc/conv_bf16.hip, launch by
+launch through the C ABI. The kernel is NOT on the default route (measured slower inside the step: profiles/r05_pw16_*,
+DESIGN.md §9) — `r3m_debug_set_pw16` switches it in; this file keeps it correct while it is off. Same MFMA order, same fp32
+accumulators, one rounding: the bf16 results must be BIT-IDENTICAL; the BatchNorm partial rows are summed in row pairs (packed
+fp32 adds) and may differ at fp32 level."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+# (N, H, Ci, Co, k, stride, pad): pointwise / gather / window forms, ragged tails, more row panels than CUs
+CASES = [(2, 56, 64, 64, 1, 1, 0), (2, 56, 64, 256, 1, 1, 0), (2, 56, 256, 64, 1, 1, 0), (2, 56, 128, 128, 3, 2, 1),
+         (2, 28, 128, 512, 1, 1, 0), (2, 56, 256, 512, 1, 2, 0), (3, 14, 256, 1024, 1, 1, 0), (3, 14, 512, 512, 3, 2, 1),
+         (5, 7, 512, 2048, 1, 1, 0), (5, 7, 2048, 512, 1, 1, 0), (1, 11, 64, 192, 3, 2, 1), (7, 5, 192, 64, 1, 1, 0),
+         (40, 56, 256, 64, 1, 1, 0), (33, 28, 128, 512, 1, 1, 0), (2, 28, 128, 128, 3, 1, 1), (3, 14, 256, 256, 3, 1, 1),
+         (5, 7, 512, 512, 3, 1, 1), (3, 9, 64, 64, 3, 1, 1), (84, 28, 128, 128, 3, 1, 1), (5, 16, 128, 64, 3, 1, 1), (1, 5, 64, 256, 3, 1, 1)]
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.fixture()
+def restore_mode(hip):
+    old = hip.r3m_debug_set_pw16(0)
+    yield
+    hip.r3m_debug_set_pw16(old)
+
+
+def test_default_route_is_the_per_tile_family(hip):
+    old = hip.r3m_debug_set_pw16(0)
+    hip.r3m_debug_set_pw16(old)
+    assert old == 0, "the persistent bf16 kernel is an opt-in experiment (DESIGN.md §9): the shipped default must stay 0"
+
+
+@pytest.mark.parametrize("mode", [1, 3], ids=["pointwise+gather", "+window"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N{}_H{}_{}to{}_k{}s{}p{}".format(*c))
+def test_persistent_kernel_bit_identical(hip, restore_mode, case, mode):
+    L = hip
+    N, H, Ci, Co, k, s, p = case
+    Ho = (H + 2 * p - k) // s + 1
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn((N, H, H, Ci), device=DEV, generator=g).bfloat16()
+    w32 = torch.randn((Co, k, k, Ci), device=DEV, generator=g) * 0.05
+    w = w32.bfloat16()
+    dy = torch.randn((N, Ho, Ho, Co), device=DEV, generator=g).bfloat16()
+    rows = L.r3m_conv2d_stats_rows(N, H, H, Co, k, s, p)
+    wsb = L.r3m_conv2d_dgrad_workspace_bytes(Ci, Co, k)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    outs = {}
+    for m in (0, mode):
+        L.r3m_debug_set_pw16(m)
+        y = torch.full((N, Ho, Ho, Co), float("nan"), device=DEV).bfloat16()
+        stats = torch.full((rows, 2, Co), float("nan"), device=DEV)
+        dx = torch.full((N, H, H, Ci), float("nan"), device=DEV).bfloat16()
+        assert L.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, 1, st()) == 0, L.r3m_last_error()
+        assert L.r3m_conv2d_dgrad_dt(dy.data_ptr(), w32.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, k, s, p, 1, st()) == 0, L.r3m_last_error()
+        torch.cuda.synchronize()
+        outs[m] = (y, stats, dx)
+    y0, s0, dx0 = outs[0]
+    y1, s1, dx1 = outs[mode]
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16))
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=1e-4 * float(s0.abs().max()))

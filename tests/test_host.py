@@ -260,3 +260,21 @@ def test_upload_small_keeps_values_and_dtype_on_a_cpu_target():
     out = _lib.upload_small(t, "cpu", torch.int32)
     assert out.dtype == torch.int32 and torch.equal(out.to(torch.int64), t)
     assert torch.equal(_lib.upload_small(t, torch.device("cpu")), t)
+
+
+def test_pick_slot_keeps_live_forwards():
+    """Slot choice of the encoder's arena ring: forwards without a backward never evict a forward that awaits one."""
+    from r3m_amd.encoder import _pick_slot
+    # one slot, nothing live: everything runs in slot 0; the cursor only moves for saved forwards
+    assert _pick_slot([False], 0, True) == (0, 0)
+    assert _pick_slot([False], 0, False) == (0, 0)
+    # one slot, live: a saved forward evicts it (its backward then raises and names max_live_forwards), an unsaved one goes to scratch
+    assert _pick_slot([True], 0, True) == (0, 0)
+    assert _pick_slot([True], 0, False) == (-1, 0)
+    # two slots: free slots first, in cursor order
+    assert _pick_slot([False, False], 0, True) == (0, 1)
+    assert _pick_slot([True, False], 1, True) == (1, 0)
+    assert _pick_slot([True, False], 0, False) == (1, 0)       # inference call: takes the free slot, cursor untouched
+    assert _pick_slot([True, True], 1, True) == (1, 0)         # all live: the oldest (cursor) goes
+    assert _pick_slot([True, True], 1, False) == (-1, 1)
+    assert _pick_slot([False, True], 1, True) == (0, 1)

@@ -120,7 +120,7 @@ def _worker(rank, world, port, q):
         conv = m3.convnet
         fired = []
 
-        def fake_forward(x, training, crop=None):
+        def fake_forward(x, training, crop=None, saved=False):
             conv._last_forward = (0, 0)
             return torch.ones((x.shape[0], conv.outdim))
 

@@ -81,7 +81,7 @@ def run_case(case, do_time):
         outs[mode] = (y.clone(), stats.clone(), dx.clone())
         if do_time:
             times[mode] = (timed(fwd), timed(dg))
-    L.r3m_debug_set_pw16(MODE)
+    L.r3m_debug_set_pw16(0)
     names = ("y", "stats", "dx")
     def same(n, a, b):
         if n == "stats":      # the big-tile kernel sums row PAIRS (packed fp32 adds): fp32-level differences in the partial rows
@@ -152,7 +152,7 @@ def step():
                     m, _ = tr.update(net, (get(), langs), i)
                 torch.cuda.synchronize()
                 res[mode].append((time.perf_counter() - t0) * 100.0)
-        L.r3m_debug_set_pw16(MODE)
+        L.r3m_debug_set_pw16(0)
         print(f"{name}: per-tile kernels {' '.join(f'{v:.2f}' for v in res[0])} ms   persistent {' '.join(f'{v:.2f}' for v in res[1])} ms", flush=True)
         del model, net, tr
         torch.cuda.empty_cache()
@@ -197,7 +197,7 @@ def report():
             a = agg.setdefault(k, {0: [0, 0.0], 1: [0, 0.0]})[mode]
             a[0] += 1
             a[1] += float(r["ms"])
-    L.r3m_debug_set_pw16(1)
+    L.r3m_debug_set_pw16(0)
     print("cls         M     N     K taps n/step  ms/launch per-tile -> persistent   ms/step delta")
     tot = 0.0
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0][1]):
