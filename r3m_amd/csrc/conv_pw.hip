@@ -309,6 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   auto pre_piece = [&](auto pc_c) __attribute__((always_inline)) {
     if constexpr (PRE) {
       constexpr int pc = decltype(pc_c)::value;
+      if (R3M_PROBE(p) & 16) return;                      // timing probe: no epilogue operand loads (stale registers; wrong results)
       // the row stride is made opaque here so that the scalar row offsets of a tile are s_mul'ed where they are used instead of
       // being hoisted out of the tile loop (they do not fit the SGPR file and would be reloaded with v_readlane)
       int ncb = Nc * 4;
@@ -368,8 +369,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
             }
           }
         if constexpr (PRE && PF != 0) {
-          // slot s of this step carries operand piece (PF - 1) * NST / 2 + s / 2 (even slots; the DMA pieces ride on the odd ones)
           constexpr int slot = g * 4 + j;
+          // slot s of this step carries operand piece (PF - 1) * NST / 2 + s / 2 (even slots; the DMA pieces ride on the odd ones).
+          // (Round 5: all pieces on the step's FIRST slots, two per slot — so that the last one has most of a K step instead of two
+          // slots to come back from HBM before the step's vmcnt(0) — measured no different, launch by launch and in the step:
+          // the CU's other block covers the wait. profiles/r05_rmw_dgrad.txt)
           if constexpr ((slot & 1) == 0 && (slot >> 1) < NST / 2) {
             if (do_pf) {
               __builtin_amdgcn_sched_barrier(0);

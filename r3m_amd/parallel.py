@@ -270,6 +270,36 @@ class DistributedR3M(nn.Module):
         self.sync.broadcast(t, src=0)
         return t
 
+    def check_replicas(self, raise_on_mismatch=True):
+        """Are the replicas still identical? Every rank applies the same averaged gradients to the same parameters, so the flat
+        parameter buffers must stay BIT-identical across ranks; nothing re-checks that after construction unless this is called
+        (the training loop does at every snapshot). Compares a float64 (sum, sum of squares) stamp of each owner's parameters with
+        two small all-reduces (MIN, MAX); BatchNorm running statistics differ by design (per-rank statistics, as the reference's
+        DataParallel normalises per replica chunk; snapshots carry rank 0's) and are only reported. Returns
+        {"params_identical": bool, "param_spread": max |max - min| / (|max| + tiny), "bn_buffer_spread": same for the buffers}."""
+        out = {"params_identical": True, "param_spread": 0.0, "bn_buffer_spread": 0.0}
+        if not self.sync.active:
+            return out
+
+        def spread(t):
+            d = t.detach().double()
+            stamp = torch.stack([d.sum(), (d * d).sum()])
+            lo, hi = stamp.clone(), stamp.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.sync.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.sync.group)
+            return float(((hi - lo).abs() / (hi.abs() + 1e-300)).max()), bool(torch.equal(lo, hi))
+
+        for owner in self._owners():
+            sp, same = spread(owner.flat_params())
+            out["param_spread"] = max(out["param_spread"], sp)
+            out["params_identical"] = out["params_identical"] and same
+        out["bn_buffer_spread"] = spread(self.module.convnet._flat_b)[0]
+        if raise_on_mismatch and not out["params_identical"]:
+            raise RuntimeError(f"r3m_amd.DistributedR3M: parameter replicas have diverged across ranks (relative spread of the "
+                               f"stamp {out['param_spread']:.3e}): a rank skipped a step, stepped outside finish_gradient_sync(), "
+                               f"or loaded different weights after construction")
+        return out
+
     def finish_gradient_sync(self):
         """Call after backward, before the optimizer step: waits for the slices launched during backward (and reduces the
         head gradients now if no encoder backward ran, e.g. a frozen encoder)."""

@@ -104,6 +104,10 @@ class Workspace:
                     batch_f, batch_langs = next(self.val_loader)
                     metrics, st = trainer.update(self.model, (batch_f, list(batch_langs)), self.global_step, eval=True)
                     self.logger.log_metrics(metrics, self.global_step, ty='eval')
+                    if hasattr(self.model, "check_replicas"):
+                        # every rank (two tiny collectives): the snapshot below is rank 0's — parameters must be the same bits on
+                        # every rank; BatchNorm running statistics are per rank by design, the snapshot carries rank 0's
+                        self.model.check_replicas()
                     if self.rank == 0:
                         print("EVAL", self.global_step, metrics)
                         self.save_snapshot()

@@ -33,6 +33,23 @@ def _worker(rank, world, port, q):
         ref = m.convnet.flat_params().clone()
         dist.broadcast(ref, src=0)
         assert torch.equal(ref, m.convnet.flat_params())
+        # replicas identical after construction; BatchNorm buffers too (broadcast). A rank that drifts is caught
+        chk = net.check_replicas()
+        assert chk["params_identical"] and chk["param_spread"] == 0.0 and chk["bn_buffer_spread"] == 0.0, chk
+        keep = (m.convnet.flat_params()[5].clone(), m.convnet._flat_b[3].clone())
+        if rank == 1:
+            m.convnet.flat_params()[5] += 1.0
+            m.convnet._flat_b[3] += 0.5                     # running statistics may differ (per-rank by design): reported, not an error
+        chk = net.check_replicas(raise_on_mismatch=False)
+        assert not chk["params_identical"] and chk["param_spread"] > 0 and chk["bn_buffer_spread"] > 0, chk
+        try:
+            net.check_replicas()
+            raise AssertionError("diverged replicas were accepted")
+        except RuntimeError as e:
+            assert "diverged" in str(e)
+        m.convnet.flat_params()[5] = keep[0]               # (the stamp is bit-sensitive: p + 1 - 1 would not pass)
+        m.convnet._flat_b[3] = keep[1]
+        assert net.check_replicas()["params_identical"]
         # emulate the encoder backward: fill the flat gradient buffer stage by stage and fire the stage hook
         g = m.convnet.flat_grads()
         n = g.numel()
