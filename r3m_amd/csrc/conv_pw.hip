@@ -122,10 +122,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   static_assert(BM / WM == 64 && (TN == 1 || TN == 2) && (NW == 4 || NW == 8), "wave tile is 64 rows x 32 TN columns");
   constexpr int STAGE = (BM + BN) * 32;                 // floats per stage: {A[BM][32], B[BN][32]}, 128-byte rows
   constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW), NP = AJ + BJ;   // DMA pieces (8 rows each) per wave and stage
-  static_assert(AJ >= 1 && BJ >= 1 && NP <= 8, "a wave stages whole DMA instructions, at most one per odd MFMA slot");
+  static_assert(AJ >= 1 && BJ >= 1 && (NP <= 8 || BURST), "a wave stages whole DMA instructions, at most one per odd MFMA slot (burst: any number)");
   constexpr int NST = 8 * TN;                           // dwordx4 stores per wave tile (a store covers 64 / (8 TN) rows)
+  // BatchNorm statistics rows (EPI_STATS) are per SR result rows whatever the tile (gather_gemm_grid_m): R of them per tile
+  constexpr int SR = BN >= 128 ? 128 : 256, R = BM / SR;
+  static_assert(R >= 1 && WM % R == 0 && (WM / R) * 64 == SR, "wave rows nest in statistics rows");
+  // LDS: [2 stages][one slab of 8 rows x CW floats per wave]. Nothing else: the statistics of a wave (2 x CW floats) and the next
+  // tile ticket wait in the slabs between the end of a tile's stores and the next barrier (see epilogue1 / epilogue2) — the
+  // 512 x 64 tile fills the CU's 160 KB to the byte.
   extern __shared__ __attribute__((aligned(128))) float smem[];
-  float* red = smem + 2 * STAGE;                        // [WM][2][BN]: BatchNorm statistics of the wave rows (EPI_STATS)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -339,7 +344,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
     using SD = std::integral_constant<int, STG_M ^ 1>;
     // fragments of group g + 1 are requested before the MFMAs of group g (two register sets; one where the prefetched epilogue
     // operands of EPI_BNRED | EPI_MASKED_ADD leave no room: 64 accumulators + 128 operands)
-    constexpr int FB = (MADD && BNR) ? 1 : 2;
+    // (likewise the 512-row gather tile with EPI_BNRED: 64 accumulators + 64 operands + the row state of 8 staged rows per lane)
+    constexpr int FB = ((MADD && BNR) || (GATHER && BNR && AJ > 4)) ? 1 : 2;
     f32x4 af[FB][2], bf[FB][TN];
     auto frag_load = [&](auto g_c) __attribute__((always_inline)) {
       constexpr int g = decltype(g_c)::value;
@@ -406,7 +412,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   // order, so the slab needs no barrier; read-modify-write operands are in pg / py / pgm / pym by now (their loads were waited
   // for with the K step's DMA).
   constexpr int CW = TN * 32;                             // columns of a wave tile = floats per slab row
-  float* slab = smem + 2 * STAGE + WM * 2 * BN + wave_s * (8 * CW);
+  float* const slabs = smem + 2 * STAGE;
+  float* slab = slabs + wave_s * (8 * CW);
   float* slab_w = slab + 4 * lh * CW + lrow;              // + (e CW + tn 32): element (row 4 lh + e, column tn 32 + lrow)
   const float* slab_r = slab + srow * CW + scol;          // + i RPS CW: row i RPS + srow, columns scol .. +3
   const int bp0 = 4 * srow;                               // ds_bpermute byte address of lane `srow` (+ 4 x the store's first row)
@@ -424,6 +431,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   auto epilogue1 = [&](int emt, int ent) __attribute__((always_inline)) {
     const int m0 = emt * BM, n0 = ent * BN;
     if (R3M_PROBE(p) & 4) return;                         // timing probes (probe builds only; wrong results)
+    float st_s[TN], st_ss[TN];
     if ((EPI & EPI_STATS) != 0 && !(R3M_PROBE(p) & 2)) {
       // same summation order as gg_stats (conv_dev.h): rows >= M were staged as zeros and add nothing
 #pragma unroll
@@ -437,13 +445,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
             s += v;
             ss = fmaf(v, v, ss);
           }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (lane < 32) {
-          const int c = (wn * TN + tn) * 32 + lane;
-          red[(wm * 2 + 0) * BN + c] = s;
-          red[(wm * 2 + 1) * BN + c] = ss;
-        }
+        st_s[tn] = s + __shfl_xor(s, 32);
+        st_ss[tn] = ss + __shfl_xor(ss, 32);
       }
     }
     const int rows_valid = min(BM, p.M - m0);
@@ -495,6 +498,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       }
       __builtin_amdgcn_wave_barrier();                    // the chunk's slab reads are issued before the next chunk's writes
     });
+    if ((EPI & EPI_STATS) != 0 && !(R3M_PROBE(p) & 2)) {
+      // the wave's column sums wait in ITS OWN slab, [2][CW], for epilogue2 (after the next barrier); a wave's LDS accesses execute in
+      // order, so they land behind the slab traffic above, and the slab is next written by the next tile's epilogue1 — barriers later
+      if (lane < 32) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          slab[tn * 32 + lane] = st_s[tn];
+          slab[CW + tn * 32 + lane] = st_ss[tn];
+        }
+      }
+    }
     if constexpr (BNR) {
       // the wave's 64 rows are one partial row of the consumer BatchNorm's backward sums (geometry of bnred_partial_rows):
       // lanes l, l + LPR, l + 2 LPR, ... hold the same four columns
@@ -517,16 +531,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   // part 2 (EPI_STATS, one barrier after part 1): combine the wave rows — stats[mt][2][Nc] as the other kernels write it
   auto epilogue2 = [&](int emt, int ent) __attribute__((always_inline)) {
     if constexpr ((EPI & EPI_STATS) != 0) {
-      if (tid < BN) {
+      if (tid < R * BN) {
+        const int r = tid / BN, c = tid - r * BN;           // statistics row r of the tile, column c
+        const float* src = slabs + (c / CW) * (8 * CW) + (c % CW);    // wave column c / CW, its slab's [0][c % CW]
         float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          s += red[(w * 2 + 0) * BN + tid];
-          ss += red[(w * 2 + 1) * BN + tid];
+        for (int w = 0; w < WM / R; ++w) {                  // the wave rows of that statistics row, top to bottom
+          const float* q = src + ((r * (WM / R) + w) * WN) * (8 * CW);
+          s += q[0];
+          ss += q[CW];
         }
-        const int col = ent * BN + tid;
-        p.stats[((long long)emt * 2 + 0) * Nc + col] = s;
-        p.stats[((long long)emt * 2 + 1) * Nc + col] = ss;
+        const long long srow = (long long)emt * R + r;
+        if (srow * SR < p.M) {                              // (a tile's second statistics row may lie past M)
+          const int col = ent * BN + c;
+          p.stats[(srow * 2 + 0) * Nc + col] = s;
+          p.stats[(srow * 2 + 1) * Nc + col] = ss;
+        }
       }
     }
   };
@@ -551,7 +571,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   const bool dyn = p.tile_ctr != nullptr;
   const int xq = blockIdx.x & 7;
   unsigned* ctr = dyn ? p.tile_ctr + xq : nullptr;
-  int* nxt = reinterpret_cast<int*>(smem + 2 * STAGE + WM * 2 * BN + NW * 8 * CW);   // the next ticket, one int
+  int* nxt = reinterpret_cast<int*>(slabs + 2 * CW);     // the next ticket, one int: in wave 0's slab behind its statistics (written after
+                                                         // epilogue1 has used the slab, read after the next barrier)
   const int gridM = tiles / gridN;
   auto ticket_tile = [&](int k, int& tmt, int& tnt) -> bool {
     const int kp = k / gridN;
@@ -610,7 +631,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         aim_step(2 * cp + 1);
-        if (BURST || (R3M_PROBE(p) & 32)) {               // (probe 32: burst in every variant)
+        if constexpr (BURST) {
+          dma_all(I1{});
+          kstep(I0{}, F_{}, F_{}, P1{}, false, last);
+        } else if (R3M_PROBE(p) & 32) {                   // (probe 32: burst in every variant)
           dma_all(I1{});
           kstep(I0{}, F_{}, F_{}, P1{}, false, last);
         } else {
@@ -641,7 +665,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       } else {
         aim_step(2 * cp + 2);
       }
-      if (BURST || (R3M_PROBE(p) & 32)) {
+      if constexpr (BURST) {
+        if (do_dma) dma_all(I0{});
+        kstep(I1{}, F_{}, F_{}, P2{}, false, last);
+      } else if (R3M_PROBE(p) & 32) {
         if (do_dma) dma_all(I0{});
         kstep(I1{}, F_{}, F_{}, P2{}, false, last);
       } else {
@@ -700,7 +727,7 @@ int pw_gemm_form(const GatherGemmParams& p) {
   // 32-bit offsets: a tile's rows span at most ceil(256 / (Hg Wg)) + 1 frames of the input; one weight tile [128][T][Ci]
   if (p.Hi >= 16384 || p.Wi >= 16384 || p.Hi < 1 || p.Wi < 1 || p.Wg < 4 || p.Hg < 2) return 0;
   const long long frame = (long long)p.Hi * p.Wi * p.Ci * 4;
-  const long long span = (256 / ((long long)p.Hg * p.Wg) + 2) * frame;
+  const long long span = (512 / ((long long)p.Hg * p.Wg) + 2) * frame;     // (the largest tile has 512 rows)
   if (span >= (long long)BUF_OOB || 128LL * p.T * p.Ci * 4 >= (long long)BUF_OOB) return 0;
   if (!dense_out) {
     // strided output rows: every output pixel of the class inside the tensor, 32-bit offsets over the frames a tile spans, and the
@@ -725,6 +752,8 @@ static bool pw_burst(const GatherGemmParams& p) {
   return (p.Nc & 127) != 0 && ktot >= 2LL * p.Nc && (p.flags == EPI_STATS || p.flags == 0 || (p.flags == EPI_BNRED && !p.bn_bits));
 }
 
+static bool pw_tile512() { return R3M_ENV_INT("R3M_PW_512", 1) != 0; }   // probe builds: 0 = the 256 x 64 tile everywhere (A/B)
+
 template <int BM, int BN, int WM, int WN, bool GA, bool OS = false>
 static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   constexpr int NW = WM * WN, TN = BN / WN / 32;
@@ -736,7 +765,9 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
   const int W = tiles < slots ? tiles : slots;
   GatherGemmParams p = p_in;
   if (W < 64 || gridM < 64) p.tile_ctr = nullptr;                     // small launches: every queue needs blocks AND panels; static split
-  constexpr int LDS = (2 * (BM + BN) * 32 + WM * 2 * BN + NW * 8 * TN * 32) * 4 + 128;   // ring + statistics scratch + one 8-row store slab per wave + the ticket
+  constexpr int LDS = (2 * (BM + BN) * 32 + NW * 8 * TN * 32) * 4;   // ring + one 8-row store slab per wave (statistics and ticket wait inside the slabs)
+  static_assert(LDS <= 160 * 1024, "one CU's LDS");
+  constexpr bool BURST_ONLY = BM / (8 * NW) + BN / (8 * NW) > 8;      // more DMA pieces per wave than odd MFMA slots: built in the burst form only
 #define LAUNCH_PW(E, YB)                                                                                                            \
   do {                                                                                                                             \
     static DynLdsOptIn oi;                                                                                                         \
@@ -766,6 +797,10 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
       case EPI_BNRED: LAUNCH_PW_BURST(EPI_BNRED); return 0;
     }
   }
+  if constexpr (BURST_ONLY) {
+    set_last_error("pw_gemm: form not built");
+    return 1;
+  } else
   switch (p.flags) {
     case 0: LAUNCH_PW(0, false); break;
     case EPI_STATS: LAUNCH_PW(EPI_STATS, false); break;
@@ -798,6 +833,9 @@ int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   if (form == 1 && !wide && R3M_ENV_INT("R3M_PW_N128", 0)) return launch_pw_shape<128, 64, 2, 2, false>(p, s);
 #endif
   if (form == 3) return wide ? launch_pw_shape<128, 128, 2, 2, true, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true, true>(p, s);
+  // 64-channel outputs, contracting launches (the burst form: conv1 / conv2 forward, conv2 / conv3 dgrad of layer1): 512 x 64 tile, eight
+  // waves of 64 x 64 like the 128-wide kernel's — half the fragment reads and barriers per MFMA of the 256 x 64 tile's 64 x 32 waves
+  if (!wide && pw_burst(p) && pw_tile512()) return form == 2 ? launch_pw_shape<512, 64, 8, 1, true>(p, s) : launch_pw_shape<512, 64, 8, 1, false>(p, s);
   if (form == 2) return wide ? launch_pw_shape<128, 128, 2, 2, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true>(p, s);
   return wide ? launch_pw_shape<128, 128, 2, 2, false>(p, s) : launch_pw_shape<256, 64, 4, 2, false>(p, s);
 }
