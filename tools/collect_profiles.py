@@ -27,6 +27,12 @@ for prec in ("fp32", "bf16"):
     if os.path.exists(csvf):
         out = subprocess.run([sys.executable, "tools/launch_report.py", csvf, "20"], capture_output=True, text=True).stdout
         open(os.path.join(P, f"{tag}_launch_report_{prec}.txt"), "w").write(out)
+        out = subprocess.run([sys.executable, "tools/launch_report.py", csvf, "20", "--roofs", prec], capture_output=True, text=True).stdout
+        open(os.path.join(P, f"{tag}_tworoof_{prec}.txt"), "w").write(out)
+for prec in ("fp32", "bf16"):
+    src = os.path.join(G, f"power_{prec}.txt")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_power_{prec}.txt"))
 log = os.path.join(G, "pytest_all.log")
 if os.path.exists(log):
     lines = [l for l in open(log, errors="replace") if l.startswith(("PASSED", "FAILED", "ERROR")) or " passed" in l or " failed" in l]

@@ -23,6 +23,19 @@ $B --size 18 --clips-per-gpu 512 --precision bf16 --steps 10 --warmup 3 --no-cpu
 $B --encoder-only-frames 256 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/cfg_enc256_fp32.json 2>/dev/null
 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --langweight 1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/cfg_c3_torchrun_1rank_rccl.json 2> gpurun_out/torchrun.err; echo "torchrun rc=$?"
 $B --gpus 1 --force-launcher --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/cfg_c1_selfspawn_1rank_rccl.json 2> gpurun_out/selfspawn.err; echo "self-spawn rc=$?"
+# board power and clocks while the fp32 / bf16 steps run (a separate run: the sampler shares the host with the launcher thread)
+for t in "fp32:" "bf16:--precision bf16 --langweight 1"; do
+  tag=${t%%:*}; args=${t#*:}
+  ( $B $args --steps 60 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/power_${tag}_bench.json 2>/dev/null ) &
+  bp=$!
+  : > gpurun_out/power_$tag.txt
+  for i in $(seq 60); do
+    kill -0 $bp 2>/dev/null || break
+    rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | tr -s ' ' | tr '\n' ';' >> gpurun_out/power_$tag.txt; echo >> gpurun_out/power_$tag.txt
+    sleep 0.5
+  done
+  wait $bp
+done
 for t in "fp32:" "bf16:--precision bf16" "r34c4:--size 34 --clips-per-gpu 512 --precision bf16 --doaug rctraj"; do
   tag=${t%%:*}; args=${t#*:}
   rm -rf /tmp/kt
