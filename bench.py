@@ -267,12 +267,33 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
             trainer.update(net, (get_frames(), langs), 0)
             torch.cuda.synchronize()
             prewarm_steps += 1
+    # Live kernel timing brackets conv GEMM launches with HIP events (two records per launch: a few microseconds of stream time each,
+    # 2.8 ms per ResNet-50 step with all 167 launches bracketed). The roofline needs the DOMINANT class only: the LAST warm-up step
+    # brackets all four classes (picks the dominant one and supplies the per-launch averages of the other three), the timed steps
+    # bracket that class alone. With --launch-csv (evidence runs: per-shape report of every launch) the timed steps bracket all.
+    warm_ms, warm_launches, warm_flops, warm_bytes = None, None, None, None
     for i in range(warmup):
+        probe = kernel_timing and not launch_csv and i == warmup - 1
+        if probe:
+            torch.cuda.synchronize()
+            L.r3m_profile_classes(0xF)
+            L.r3m_profile_enable(1)
         trainer.update(net, (get_frames(), langs), i)
+        if probe:
+            torch.cuda.synchronize()
+            warm_ms, warm_launches, warm_flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
+            _lib.check(L.r3m_profile_collect(warm_ms, warm_launches, warm_flops), "profile_collect")
+            warm_bytes = (C.c_double * 4)()
+            _lib.check(L.r3m_profile_collect_bytes(warm_bytes), "profile_collect_bytes")
+            L.r3m_profile_enable(0)
+    timed_classes = 0xF
+    if warm_ms is not None and max(warm_ms) > 0:
+        timed_classes = 1 << max(range(4), key=lambda k: warm_ms[k])
     total_steps = prewarm_steps + warmup + steps
     sync = getattr(net, "sync", None)
     if sync is not None:
         sync.time_waits(True)                           # HIP events on the compute stream around the waits for RCCL
+    L.r3m_profile_classes(timed_classes)
     L.r3m_profile_enable(1 if kernel_timing else 0)
     if launch_csv and rank == 0:
         _lib.check(L.r3m_profile_dump_to(launch_csv.encode()), "profile_dump_to")
@@ -285,6 +306,7 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
     ms, launches, flops = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
     _lib.check(L.r3m_profile_collect(ms, launches, flops), "profile_collect")
     L.r3m_profile_enable(0)
+    L.r3m_profile_classes(0xF)
     L.r3m_profile_dump_to(None)
     comm_exposed_ms = sync.exposed_ms() / steps if sync is not None else None
     if sync is not None:
@@ -316,7 +338,14 @@ def measure(w, steps, warmup, prewarm_seconds, ctx, kernel_timing=True, launch_c
                 kernels.append({"kernel": KCLASS[k], "launches_per_step": launches[k] / steps,
                                 "avg_launch_ms": ms[k] / launches[k], "ms_per_step": ms[k] / steps,
                                 "tflops": flops[k] / (ms[k] * 1e-3) / 1e12,
-                                "algorithmic_GBps": bytes_k[k] / (ms[k] * 1e-3) / 1e9})
+                                "algorithmic_GBps": bytes_k[k] / (ms[k] * 1e-3) / 1e9,
+                                "measured_over": f"the {steps} timed steps"})
+            elif warm_ms is not None and warm_launches[k]:
+                kernels.append({"kernel": KCLASS[k], "launches_per_step": float(warm_launches[k]),
+                                "avg_launch_ms": warm_ms[k] / warm_launches[k], "ms_per_step": warm_ms[k],
+                                "tflops": warm_flops[k] / (warm_ms[k] * 1e-3) / 1e12,
+                                "algorithmic_GBps": warm_bytes[k] / (warm_ms[k] * 1e-3) / 1e9,
+                                "measured_over": "the last warm-up step (not bracketed inside the timed steps)"})
         dom = max(range(4), key=lambda k: ms[k])
         ach = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         bf16 = precision == "bf16"

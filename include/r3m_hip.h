@@ -46,6 +46,9 @@ int r3m_debug_set_pw16(int mode);
 int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
                          int* routes, int cap);
 void r3m_profile_enable(int on);
+/* which kernel classes are bracketed while profiling is on: bit k = class k (0 conv fwd/dgrad 128-wide, 1 64-wide, 2 / 3 the weight
+   gradients); default all. Each bracket costs the stream two event records. Returns the old mask. */
+unsigned r3m_profile_classes(unsigned mask);
 int r3m_profile_collect(double* ms, long long* launches, double* flops);
 int r3m_profile_collect_bytes(double* bytes);     /* algorithmic HBM bytes per class (operands + results once) of the launches of the last collect() */
 int r3m_profile_dump_to(const char* host_path);   /* also write one CSV row per launch at collect(); NULL/"" stops */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "r3m_debug_set_pw16": (c_i, [c_i]),
     "r3m_debug_conv_route": (c_i, [c_i] * 12 + [C.POINTER(c_i), c_i]),
     "r3m_profile_enable": (None, [c_i]),
+    "r3m_profile_classes": (C.c_uint, [C.c_uint]),
     "r3m_profile_collect": (c_i, [C.POINTER(c_d), C.POINTER(c_ll), C.POINTER(c_d)]),
     "r3m_profile_collect_bytes": (c_i, [C.POINTER(c_d)]),
     "r3m_profile_dump_to": (c_i, [C.c_char_p]),
