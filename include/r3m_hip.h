@@ -91,6 +91,10 @@ int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u
  * that produces its dz (EPI_BNRED; default for fp32 plans), 0 = stand-alone reduce passes (default for bf16 plans, where the
  * fused form measured slower). Both schedules compute the same sums (different summation order). Returns the previous value. */
 int r3m_resnet_set_fused_bn_reduce(r3m_resnet_t h, int on);
+/* Per-plan switch: 1 (default) = the two BatchNorms that feed a downsample block's add + ReLU (the block's last one and the downsample
+ * branch's) run their backward passes as ONE launch each — they see the same masked output gradient, which is then read once instead
+ * of twice; 0 = separate passes. Bit-identical gradients either way. Returns the previous value. */
+int r3m_resnet_set_bn_pair(r3m_resnet_t h, int on);
 int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
                         int stage_end, int accumulate, r3m_stream_t stream);
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "r3m_resnet_forward": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_i, c_f]),
     "r3m_resnet_forward_crop": (c_i, [C.c_void_p, c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_f]),
     "r3m_resnet_set_fused_bn_reduce": (c_i, [C.c_void_p, c_i]),
+    "r3m_resnet_set_bn_pair": (c_i, [C.c_void_p, c_i]),
     "r3m_resnet_backward": (c_i, [C.c_void_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f]),
     "r3m_conv2d_stats_rows": (c_i, [c_i] * 7),
     "r3m_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f] + [c_i] * 8 + [c_f]),

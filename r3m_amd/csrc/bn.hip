@@ -650,6 +650,160 @@ int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// pass 2 for the TWO BatchNorms of a downsample block's tail in one launch (round 5). out = relu(bn3(y3) + bn_d(yd)): both BatchNorms
+// see the same masked gradient g = dOut * [out > 0], so the stand-alone passes read dOut and the mask bits twice. Here they are read
+// once: dY3 = scale3 (g - c1_3 - yhat3 c2_3), dYd = scale_d (g - c1_d - yhat_d c2_d). Same arithmetic per element as two launches of
+// bn_bwd_apply_kernel (bit-identical results); 20 instead of 24 bytes per element in fp32 (10 / 12 in bf16).
+// A / B: {scale, mean, invstd, c1, c2} of the two BatchNorms (the mask comes as bits: block outputs always have them).
+// ---------------------------------------------------------------------------------------------------------
+struct BnApplyCoef { const float* scale; const float* mean; const float* invstd; const float* c1; const float* c2; };
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dZ, const unsigned* __restrict__ Zbits,
+                                                             const T* __restrict__ YA, BnApplyCoef A, T* __restrict__ dYA,
+                                                             const T* __restrict__ YB, BnApplyCoef B, T* __restrict__ dYB,
+                                                             long long n4, int c4mask, int span) {
+  long long i = (long long)BN_BID(4) * span + threadIdx.x;
+  if (i >= n4) return;
+  const long long end = min((long long)(BN_BID(4) + 1) * span, n4);
+  const int c = ((int)(i & c4mask)) * 4;
+  const f32x4 scA = ld4(A.scale + c), muA = ld4(A.mean + c), isA = ld4(A.invstd + c), k1A = ld4(A.c1 + c), k2A = ld4(A.c2 + c);
+  const f32x4 scB = ld4(B.scale + c), muB = ld4(B.mean + c), isB = ld4(B.invstd + c), k1B = ld4(B.c1 + c), k2B = ld4(B.c2 + c);
+  for (; i < end; i += 256) {
+    const f32x4 ya = lds4(YA + i * 4);
+    const f32x4 yb = lds4(YB + i * 4);
+    const f32x4 dz = lds4(dZ + i * 4);
+    const unsigned nb = (Zbits[i >> 3] >> (4 * (int)(i & 7))) & 15u;
+    f32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = ((nb >> e) & 1u) ? dz[e] : 0.f;
+      const float yha = (ya[e] - muA[e]) * isA[e];
+      const float yhb = (yb[e] - muB[e]) * isB[e];
+      oa[e] = scA[e] * (g - k1A[e] - yha * k2A[e]);
+      ob[e] = scB[e] * (g - k1B[e] - yhb * k2B[e]);
+    }
+    sts4(dYA + i * 4, oa);
+    sts4(dYB + i * 4, ob);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply2_16_kernel(const bf16_t* __restrict__ dZ, const unsigned* __restrict__ Zbits,
+                                                                const bf16_t* __restrict__ YA, BnApplyCoef A, bf16_t* __restrict__ dYA,
+                                                                const bf16_t* __restrict__ YB, BnApplyCoef B, bf16_t* __restrict__ dYB,
+                                                                long long n8, int c8mask, int span) {
+  long long i = (long long)BN_BID(4) * span + threadIdx.x;
+  if (i >= n8) return;
+  const long long end = min((long long)(BN_BID(4) + 1) * span, n8);
+  const int c = ((int)(i & c8mask)) * 8;
+  const f32x8 scA = ld8f(A.scale + c), muA = ld8f(A.mean + c), isA = ld8f(A.invstd + c), k1A = ld8f(A.c1 + c), k2A = ld8f(A.c2 + c);
+  const f32x8 scB = ld8f(B.scale + c), muB = ld8f(B.mean + c), isB = ld8f(B.invstd + c), k1B = ld8f(B.c1 + c), k2B = ld8f(B.c2 + c);
+  for (; i < end; i += 256) {
+    const f32x8 ya = ld8(YA + i * 8);
+    const f32x8 yb = ld8(YB + i * 8);
+    const f32x8 dz = ld8(dZ + i * 8);
+    const unsigned nb = (Zbits[i >> 2] >> (8 * (int)(i & 3))) & 255u;
+    f32x8 g, oa, ob;
+    FOR8(g, ((nb >> e) & 1u) ? dz.lo[e] : 0.f, ((nb >> (4 + e)) & 1u) ? dz.hi[e] : 0.f)
+    FOR8(oa, scA.lo[e] * (g.lo[e] - k1A.lo[e] - ((ya.lo[e] - muA.lo[e]) * isA.lo[e]) * k2A.lo[e]),
+         scA.hi[e] * (g.hi[e] - k1A.hi[e] - ((ya.hi[e] - muA.hi[e]) * isA.hi[e]) * k2A.hi[e]))
+    FOR8(ob, scB.lo[e] * (g.lo[e] - k1B.lo[e] - ((yb.lo[e] - muB.lo[e]) * isB.lo[e]) * k2B.lo[e]),
+         scB.hi[e] * (g.hi[e] - k1B.hi[e] - ((yb.hi[e] - muB.hi[e]) * isB.hi[e]) * k2B.hi[e]))
+    st8(dYA + i * 8, oa);
+    st8(dYB + i * 8, ob);
+  }
+}
+
+// pass 1 for the same pair (bf16 plans, where every first pass is stand-alone): sum(g) is common, sum(g yhat) per BatchNorm; dOut and the
+// mask bits are read once. Two partial sets [rows][2][C], the second `set_stride` floats behind the first; same block geometry and
+// summation order as bn_bwd_reduce16_kernel (bit-identical partials).
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_16_kernel(const bf16_t* __restrict__ dZ, const unsigned* __restrict__ Zbits,
+                                                                 const bf16_t* __restrict__ YA, const float* __restrict__ meanA,
+                                                                 const float* __restrict__ invstdA, const bf16_t* __restrict__ YB,
+                                                                 const float* __restrict__ meanB, const float* __restrict__ invstdB,
+                                                                 float* __restrict__ partials, long long set_stride, long long rows, int C,
+                                                                 int cpb8, int rows_per_block) {
+  __shared__ f32x4 red[6][256];
+  const int tcol = threadIdx.x % cpb8, trow = threadIdx.x / cpb8;
+  const int rpp = 256 / cpb8;
+  const int c = (blockIdx.y * cpb8 + tcol) * 8;
+  const long long r_begin = (long long)BN_BID(2) * rows_per_block;
+  long long r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const f32x8 muA = ld8f(meanA + c), isA = ld8f(invstdA + c), muB = ld8f(meanB + c), isB = ld8f(invstdB + c);
+  f32x8 s1, s2a, s2b;
+  FOR8(s1, 0.f, 0.f)
+  FOR8(s2a, 0.f, 0.f)
+  FOR8(s2b, 0.f, 0.f)
+  for (long long r = r_begin + trow; r < r_end; r += rpp) {
+    const long long off = r * C + c;
+    const f32x8 ya = ld8(YA + off);
+    const f32x8 yb = ld8(YB + off);
+    const f32x8 dz = ld8(dZ + off);
+    const unsigned nb = (Zbits[off >> 5] >> (int)(off & 31)) & 255u;
+    f32x8 g;
+    FOR8(g, ((nb >> e) & 1u) ? dz.lo[e] : 0.f, ((nb >> (4 + e)) & 1u) ? dz.hi[e] : 0.f)
+    FOR8(s1, s1.lo[e] + g.lo[e], s1.hi[e] + g.hi[e])
+    FOR8(s2a, fmaf(g.lo[e], (ya.lo[e] - muA.lo[e]) * isA.lo[e], s2a.lo[e]), fmaf(g.hi[e], (ya.hi[e] - muA.hi[e]) * isA.hi[e], s2a.hi[e]))
+    FOR8(s2b, fmaf(g.lo[e], (yb.lo[e] - muB.lo[e]) * isB.lo[e], s2b.lo[e]), fmaf(g.hi[e], (yb.hi[e] - muB.hi[e]) * isB.hi[e], s2b.hi[e]))
+  }
+  red[0][threadIdx.x] = s1.lo; red[1][threadIdx.x] = s1.hi;
+  red[2][threadIdx.x] = s2a.lo; red[3][threadIdx.x] = s2a.hi;
+  red[4][threadIdx.x] = s2b.lo; red[5][threadIdx.x] = s2b.hi;
+  __syncthreads();
+  if (trow == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s1.lo += red[0][k * cpb8 + tcol]; s1.hi += red[1][k * cpb8 + tcol];
+      s2a.lo += red[2][k * cpb8 + tcol]; s2a.hi += red[3][k * cpb8 + tcol];
+      s2b.lo += red[4][k * cpb8 + tcol]; s2b.hi += red[5][k * cpb8 + tcol];
+    }
+    float* p1 = partials + ((long long)BN_BID(2) * 2 + 0) * C + c;
+    float* p2 = partials + ((long long)BN_BID(2) * 2 + 1) * C + c;
+    st4(p1, s1.lo); st4(p1 + 4, s1.hi);
+    st4(p2, s2a.lo); st4(p2 + 4, s2a.hi);
+    st4(p1 + set_stride, s1.lo); st4(p1 + set_stride + 4, s1.hi);
+    st4(p2 + set_stride, s2b.lo); st4(p2 + set_stride + 4, s2b.hi);
+  }
+}
+
+// true: launched (bf16 plans with C a multiple of 8); false: the caller runs two stand-alone first passes
+bool bn_bwd_reduce2_available(int C, int dt) { return use_v8(dt, C); }
+int launch_bn_bwd_reduce2(const void* dZ, const unsigned* Zbits, const void* YA, const float* coefA, const void* YB, const float* coefB,
+                          float* partials, long long set_stride, long long rows, int C, int dt, hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && use_v8(dt, C) && Zbits, "bn_bwd_reduce2: bf16 plans with mask bits only (C=%d dtype=%d)", C, dt);
+  int cpb8, rpb, nblk;
+  bwd_geometry16(rows, C, &cpb8, &rpb, &nblk);
+  R3M_REQUIRE((long long)nblk * 2 * C <= set_stride, "bn_bwd_reduce2: partial sets overlap");
+  hipLaunchKernelGGL(bn_bwd_reduce2_16_kernel, dim3(nblk, ceil_div(C / 8, cpb8)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
+                     static_cast<const bf16_t*>(YA), coefA, coefA + C, static_cast<const bf16_t*>(YB), coefB, coefB + C, partials, set_stride,
+                     rows, C, cpb8, rpb);
+  return check_launch("bn_bwd_reduce2_16");
+}
+
+// coefA / coefB: the layer's coefficient block [6][C] = {mean, invstd, scale, shift, c1, c2} (engine.hip coef())
+int launch_bn_bwd_apply2(const void* dZ, const unsigned* Zbits, const void* YA, const float* coefA, void* dYA, const void* YB,
+                         const float* coefB, void* dYB, long long rows, int C, int dt, hipStream_t s) {
+  R3M_REQUIRE(is_pow2(C) && C >= 8 && Zbits, "bn_bwd_apply2: C=%d must be a power of two >= 8 and the mask must come as bits", C);
+  const BnApplyCoef A{coefA + 2LL * C, coefA, coefA + C, coefA + 4LL * C, coefA + 5LL * C};
+  const BnApplyCoef B{coefB + 2LL * C, coefB, coefB + C, coefB + 4LL * C, coefB + 5LL * C};
+  if (use_v8(dt, C)) {
+    const long long n8 = rows * C / 8;
+    const int span8 = bn_span(C / 8, 4);
+    hipLaunchKernelGGL(bn_bwd_apply2_16_kernel, dim3(ceil_div(n8, span8)), dim3(256), 0, s, static_cast<const bf16_t*>(dZ), Zbits,
+                       static_cast<const bf16_t*>(YA), A, static_cast<bf16_t*>(dYA), static_cast<const bf16_t*>(YB), B,
+                       static_cast<bf16_t*>(dYB), n8, C / 8 - 1, span8);
+    return check_launch("bn_bwd_apply2_16");
+  }
+  R3M_REQUIRE(dt == DT_F32, "bn_bwd_apply2: dtype %d", dt);
+  const long long n4 = rows * C / 4;
+  const int span = bn_span(C / 4, C >= 512 ? 4 : 1);
+  hipLaunchKernelGGL((bn_bwd_apply2_kernel<float>), dim3(ceil_div(n4, span)), dim3(256), 0, s, static_cast<const float*>(dZ), Zbits,
+                     static_cast<const float*>(YA), A, static_cast<float*>(dYA), static_cast<const float*>(YB), B,
+                     static_cast<float*>(dYB), n4, C / 4 - 1, span);
+  return check_launch("bn_bwd_apply2");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, padding 1), NHWC. Forward keeps the window-local argmax (0..8, first maximum in
 // row-major scan order, like ATen) in one byte per output element; backward is a gather over the <= 4 windows that
 // contain an input pixel, so it needs neither atomics nor a zero-fill pass.

@@ -131,6 +131,7 @@ int plan_stage_range(Plan*, int stage, long long* off, long long* count);
 void plan_destroy(Plan*);
 int* plan_gd(Plan*);
 int plan_set_fuse_bnred(Plan*, int on);
+int plan_set_bn_pair(Plan*, int on);
 // loss.hip / adam.hip
 size_t loss_workspace_floats(int B);
 int launch_tcn_lp_loss(const float* alle, const int* perm, const int* iperm, float* dalle, float* ws, int B, int D, int l2dist,
@@ -277,6 +278,7 @@ int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u
   return plan_forward_src(*PLAN(h), nullptr, &src, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
 }
 int r3m_resnet_set_fused_bn_reduce(r3m_resnet_t h, int on) { return h ? plan_set_fuse_bnred(PLAN(h), on) : -1; }
+int r3m_resnet_set_bn_pair(r3m_resnet_t h, int on) { return h ? plan_set_bn_pair(PLAN(h), on) : -1; }
 int r3m_resnet_backward(r3m_resnet_t h, const float* dh, const float* params, float* grads, void* arena, int stage_begin,
                         int stage_end, int accumulate, r3m_stream_t stream) {
   R3M_REQUIRE(h && dh && params && grads && arena, "resnet_backward: null argument");

@@ -205,6 +205,13 @@ int launch_bn_bwd_apply(const void* dZ, const void* Zmask, const unsigned* Zbits
 int launch_bn_relu_maxpool_fwd(const void* Y, const float* scale, const float* shift, void* P, unsigned char* amax, int N, int Hi,
                                int Wi, int C, int dt, hipStream_t s);
 int bn_bwd_pool_partial_rows(int N, int Hi, int Wi, int C);
+// the two BatchNorms of a downsample block's tail (same masked gradient) in one pass; coefA / coefB = [6][C] {mean, invstd, scale, shift, c1, c2}
+int launch_bn_bwd_apply2(const void* dZ, const unsigned* Zbits, const void* YA, const float* coefA, void* dYA, const void* YB,
+                         const float* coefB, void* dYB, long long rows, int C, int dt, hipStream_t s);
+bool bn_bwd_reduce2_available(int C, int dt);
+int launch_bn_bwd_reduce2(const void* dZ, const unsigned* Zbits, const void* YA, const float* coefA, const void* YB, const float* coefB,
+                          float* partials, long long set_stride /* floats between the two partial sets */, long long rows, int C, int dt,
+                          hipStream_t s);
 int launch_bn_bwd_reduce_pool(const void* dP, const unsigned char* amax, const void* Y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, float* partials, int N, int Hi, int Wi, int C, int dt,
                               hipStream_t s);

@@ -11,6 +11,10 @@
 // stored OHWI (= logical OIHW tensors with channels_last strides, so state-dict interchange needs no copy kernels).
 #include "common.h"
 #include "augment_dev.h"
+#ifndef R3M_BN_PAIR_DEFAULT
+#define R3M_BN_PAIR_DEFAULT 1     // A/B builds: tools/build_ab.sh none variant nopair -DR3M_BN_PAIR_DEFAULT=0
+#endif
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +69,8 @@ struct Plan {
   long long col_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
   long long ctr_off = 0;    // [convs][8] + [convs][4][8] unsigned: per-XCD tile queues of the persistent kernel — the forward launch of each conv, and the (up to four: stride-2 parity classes) backward launches
   long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
+  long long E_off = -1;   // dY of a downsample block's downsample BatchNorm: written with the block's last BatchNorm backward (one pass
+                          // for both, bn_backward_pair), read by the downsample dgrad / wgrad at the END of the block (-1: no such block)
   long long arena_floats = 0;
   long long gmax = 0;
   int last_training = 1;
@@ -80,6 +86,7 @@ struct Plan {
   int dout_fused_rows = 0;  // > 0: the dgrad that wrote the running output gradient also wrote the BatchNorm-backward partials of the
                             // block that consumes it next (EPI_BNRED): that many partial rows wait in the partial buffer
   int use_side = -1;
+  int bn_pair = R3M_BN_PAIR_DEFAULT;   // the two tail BatchNorms of a downsample block share their backward passes (bn_backward_pair); 0: separate passes
   // Backward stages carry state from one r3m_resnet_backward call to the next (buffer roles, the running output gradient and — with
   // EPI_BNRED — BatchNorm partials waiting in the shared partial buffer for the NEXT block). They are only valid in the order
   // 0,1,2,3 after ONE forward: next_stage is what the following call must begin with (0 = a backward may (re)start, -1 = no
@@ -193,6 +200,8 @@ Plan* plan_create(int size, int F, int dtype) {
     if (pr > partial_max) partial_max = pr;
     pr = (long long)(i == 0 ? bn_bwd_pool_partial_rows(F, c.Ho, c.Wo, c.Co) : bn_bwd_partial_rows(M, c.Co, dtype)) * 2 * c.Co;
     if (pr > partial_max) partial_max = pr;
+    pr *= 2;                                                    // two sets: the paired first pass of a downsample block's tail (bn_backward_pair)
+    if (i > 0 && pr > partial_max) partial_max = pr;
     pr = ((long long)bnred_partial_rows(M) + 4) * 2 * c.Co;     // EPI_BNRED: one row per 64 result rows (+ one per stride-2 parity class)
     if (pr > partial_max) partial_max = pr;
     const long long welems = (long long)c.Co * c.k * c.k * c.Ci;
@@ -238,6 +247,12 @@ Plan* plan_create(int size, int F, int dtype) {
   P.ctr_off = take(5LL * (long long)P.convs.size() * 8);
   P.gmax = gmax;
   for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
+  {
+    long long emax = 0;
+    for (size_t bi = 0; bi < P.blocks.size(); ++bi)
+      if (P.blocks[bi].ds >= 0) emax = std::max(emax, act(Fll * P.blocks[bi].Ho * P.blocks[bi].Wo * P.blocks[bi].Co));
+    if (emax > 0) P.E_off = take(emax);
+  }
   P.arena_floats = off;
   return Pp;
 }
@@ -510,7 +525,8 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
 // BatchNorm(+ReLU / residual mask) backward of layer L: dZ -> dY, parameter gradients into the flat gradient buffer
 // fused_rows > 0: the dgrad that produced dZ already wrote this BatchNorm's backward partials (EPI_BNRED, sum(g) and
 // sum(g (y - mean)) per 64 rows) into the partial buffer: the stand-alone first pass is skipped
-static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY, int fused_rows = 0) {
+// first pass + combine: the parameter gradients and the two per-channel coefficients c1 / c2 the second pass needs
+static int bn_backward_sums(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, int fused_rows) {
   Plan& P = c.P;
   const long long rows = (long long)P.F * L.Ho * L.Wo;
   float* partial = c.arena + P.partial_off;
@@ -522,11 +538,44 @@ static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigne
     prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
   }
   TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
-  TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
-                                  coef(c, L, 5), c.accumulate, L.Co, c.s, fused_rows ? coef(c, L, 1) : nullptr));
-  TRY(launch_bn_bwd_apply(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4), coef(c, L, 5),
-                          dY, rows, L.Co, c.dt, c.s));
-  return 0;
+  return launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
+                                     coef(c, L, 5), c.accumulate, L.Co, c.s, fused_rows ? coef(c, L, 1) : nullptr);
+}
+static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY, int fused_rows = 0) {
+  TRY(bn_backward_sums(c, L, dZ, Zbits, fused_rows));
+  const long long rows = (long long)c.P.F * L.Ho * L.Wo;
+  return launch_bn_bwd_apply(dZ, nullptr, Zbits, c.arena + L.Y_off, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), coef(c, L, 4),
+                             coef(c, L, 5), dY, rows, L.Co, c.dt, c.s);
+}
+// The two BatchNorms that feed a downsample block's add + ReLU (its last convolution's and the downsample convolution's) see the SAME
+// masked output gradient: their second passes run as ONE launch that reads dOut and the mask bits once (bn.hip, bn_bwd_apply2).
+// The sums of the two are taken one after the other (they share the partial / accumulator scratch).
+static int bn_backward_pair(Ctx& c, const ConvSpec& L, const ConvSpec& Ld, const float* dZ, const unsigned* Zbits, float* dY, float* dYd,
+                            int fused_rows) {
+  R3M_REQUIRE(L.Co == Ld.Co && L.Ho == Ld.Ho && L.Wo == Ld.Wo && Zbits, "bn_backward_pair: the two BatchNorms must have one shape and mask bits");
+  const long long rows = (long long)c.P.F * L.Ho * L.Wo;
+  if (!fused_rows && bn_bwd_reduce2_available(L.Co, c.dt)) {
+    // both first passes are stand-alone (bf16 plans): one launch, two partial sets, then the two combines one after the other
+    Plan& P = c.P;
+    float* partial = c.arena + P.partial_off;
+    double* acc = reinterpret_cast<double*>(c.arena + P.acc_off);
+    const int prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
+    const long long set = (long long)prow * 2 * L.Co;
+    TRY(launch_bn_bwd_reduce2(dZ, Zbits, c.arena + L.Y_off, c.arena + L.coef_off, c.arena + Ld.Y_off, c.arena + Ld.coef_off, partial, set,
+                              rows, L.Co, c.dt, c.s));
+    const ConvSpec* two[2] = {&L, &Ld};
+    for (int k = 0; k < 2; ++k) {
+      const ConvSpec& Q = *two[k];
+      TRY(launch_bn_stats_reduce(partial + k * set, prow, Q.Co, acc, c.s));
+      TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + Q.gamma_off, c.grads + Q.beta_off, coef(c, Q, 4),
+                                      coef(c, Q, 5), c.accumulate, Q.Co, c.s, nullptr));
+    }
+  } else {
+    TRY(bn_backward_sums(c, L, dZ, Zbits, fused_rows));
+    TRY(bn_backward_sums(c, Ld, dZ, Zbits, 0));
+  }
+  return launch_bn_bwd_apply2(dZ, Zbits, c.arena + L.Y_off, c.arena + L.coef_off, dY, c.arena + Ld.Y_off, c.arena + Ld.coef_off, dYd, rows,
+                              L.Co, c.dt, c.s);
 }
 
 static int wgrad(Ctx& c, const ConvSpec& L, const float* X, const float* dY) {
@@ -725,11 +774,17 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
       const ConvSpec* Lprev_last = Bprev ? &P.convs[Bprev->conv[Bprev->nconv - 1]] : nullptr;
       const unsigned* prev_bits = Bprev ? reinterpret_cast<const unsigned*>(arena + Bprev->mask_off) : nullptr;
       int ai;
+      // downsample block: both tail BatchNorms in one second pass, the downsample one's dY parked in E until the end of the block
+      // (R3M_BN_PAIR=0 in probe builds: two separate passes, for A/B)
+      const bool pair = B.ds >= 0 && P.E_off >= 0 && B.nconv >= 2 && P.bn_pair && R3M_ENV_INT("R3M_BN_PAIR", 1) != 0 && P.convs[B.ds].Co >= 8;
+      float* const dYd_pair = pair ? arena + P.E_off : nullptr;
       for (int j = B.nconv - 1; j >= 1; --j) {
         const ConvSpec& L = P.convs[B.conv[j]];
         const ConvSpec& Lprev = P.convs[B.conv[j - 1]];
         float* dY = next_A(&ai);
         TRY(acquire_A(ai));
+        if (pair && j == B.nconv - 1) TRY(bn_backward_pair(c, L, P.convs[B.ds], dz, zmask, dY, dYd_pair, dz_fused));
+        else
         TRY(bn_backward(c, L, dz, zmask, dY, dz_fused));     // HBM-bound: overlaps the previous layer's wgrad
         TRY(wait_wgrads());
         TRY(dgrad(c, L, dY, Gb, 0, nullptr, nullptr, &Lprev, nullptr, &dz_fused));   // Gb = dz of Lprev's BatchNorm + its partials
@@ -745,13 +800,18 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         const ConvSpec& Ld = P.convs[B.ds];
         TRY(dgrad(c, L1, dY1, Gc, 0, nullptr, nullptr));
         TRY(wgrad_async(L1, Xin, dY1, ai));
-        int ad;
-        float* dYd = next_A(&ad);
-        TRY(acquire_A(ad));
-        TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1); always the stand-alone reduce (second consumer of dOut)
-        TRY(wait_wgrads());
-        TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
-        TRY(wgrad_async(Ld, Xin, dYd, ad));
+        if (pair) {                                     // dY of the downsample BatchNorm has been waiting in E since the block's first pass
+          TRY(dgrad(c, Ld, dYd_pair, Gc, EPI_ACCUM, nullptr, nullptr));
+          TRY(wgrad_async(Ld, Xin, dYd_pair, ai));      // (side stream: ordered behind conv1's wgrad, same event slot)
+        } else {
+          int ad;
+          float* dYd = next_A(&ad);
+          TRY(acquire_A(ad));
+          TRY(bn_backward(c, Ld, dOut, Out, dYd));        // overlaps wgrad(conv1); always the stand-alone reduce (second consumer of dOut)
+          TRY(wait_wgrads());
+          TRY(dgrad(c, Ld, dYd, Gc, EPI_ACCUM, nullptr, nullptr));
+          TRY(wgrad_async(Ld, Xin, dYd, ad));
+        }
       } else {
         // Gc = dgrad + masked residual gradient = the previous block's COMPLETE output gradient: also emit the partials of the
         // BatchNorm that will consume it (the previous block's last one, masked by that block's output bits)
@@ -828,6 +888,7 @@ void plan_destroy(Plan* P) {
 }
 int* plan_gd(Plan* P) { return &P->gd; }
 // per-plan option: 1 = BatchNorm-backward partials from the dgrad epilogues (EPI_BNRED), 0 = stand-alone reduce passes
+int plan_set_bn_pair(Plan* P, int on) { const int old = P->bn_pair; P->bn_pair = on ? 1 : 0; return old; }
 int plan_set_fuse_bnred(Plan* P, int on) { const int old = P->fuse_bnred; P->fuse_bnred = on ? 1 : 0; return old; }
 
 }  // namespace r3m

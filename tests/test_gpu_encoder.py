@@ -418,6 +418,33 @@ def test_fused_and_standalone_bn_backward_reduce_agree(hip, size, F, precision):
             assert worst_l4 <= tol4 and worst <= tol, (worst, worst_k, worst_l4)
 
 
+@pytest.mark.parametrize("size,F,precision", [(18, 5, "fp32"), (34, 3, "bf16"), (50, 4, "fp32"), (50, 3, "bf16")])
+def test_paired_bn_backward_is_bit_identical(hip, size, F, precision):
+    """Round 5: the two BatchNorms that feed a downsample block's add + ReLU see the same masked gradient; their backward passes run
+    as one launch each (second pass always; first pass too on bf16 plans). Same arithmetic per element and the same summation order
+    as the separate passes: every parameter gradient must be BIT-identical with the switch on and off, train and eval."""
+    from oracle import detgen
+    from r3m_amd import R3M, _lib
+    L = _lib.lib()
+    m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0, precision=precision)
+    _load_state(m.convnet)
+    m = m.to(DEV)
+    x = torch.from_numpy(detgen.frames("frames8", (8, 3, 224, 224)))[:F].to(DEV)
+    for training in (True, False):
+        m.train(training)
+        res = {}
+        for on in (1, 0):
+            m.encoder_opt.zero_grad()
+            h = m(x)
+            assert L.r3m_resnet_set_bn_pair(m.convnet._plans[F], on) in (0, 1)
+            cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).to(DEV)
+            (h * cw).sum().backward()
+            res[on] = {k: p.grad.detach().clone() for k, p in m.convnet.named_parameters()}
+        L.r3m_resnet_set_bn_pair(m.convnet._plans[F], 1)
+        bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+        assert not bad, (training, bad[:5])
+
+
 def test_second_forward_before_backward(hip):
     """The reference encoder is a plain autograd graph (models_r3m.py:84-100): h1 = enc(x1); h2 = enc(x2); backward through both
     works. Here a forward's activations live in a preallocated arena: with the default of one arena the FIRST forward's backward
