@@ -78,7 +78,10 @@ void prof_begin(int kclass, double flops, int M, int N, int K, int taps, hipStre
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_used == g_prof_pool.size()) {
       ProfEvent ne{};
-      if (hipEventCreate(&ne.a) != hipSuccess || hipEventCreate(&ne.b) != hipSuccess) return;
+      // timing-only events: no system-scope fence when they are recorded (hipEventDisableSystemFence) — the default flags write
+      // back and invalidate the caches at every record, which is what a bracket mostly cost the stream and the kernel that follows
+      if (hipEventCreateWithFlags(&ne.a, hipEventDisableSystemFence) != hipSuccess ||
+          hipEventCreateWithFlags(&ne.b, hipEventDisableSystemFence) != hipSuccess) return;
       g_prof_pool.push_back(ne);
     }
     e = &g_prof_pool[g_prof_used++];
