@@ -547,6 +547,8 @@ def main():
                 else:
                     out["ms_per_step_without_kernel_timing"] = r0["ms_per_step"]
                     out["kernel_timing_overhead_ms"] = round(out["ms_per_step"] - r0["ms_per_step"], 3)
+                    out["kernel_timing_overhead_note"] = ("difference of two legs run a minute apart on a power-limited part: good to about "
+                                                          "+-1 ms; the interleaved same-box A/B reads 0.3 ms (profiles/r05_event_fence_ab.txt)")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if affinity0 is not None:
