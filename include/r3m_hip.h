@@ -38,6 +38,10 @@ int r3m_debug_set_dynamic_tiles(int on);
    csrc/conv_bf16.hip; 1 = eligible launches run the persistent big-tile kernel of csrc/conv_pw16.hip (pointwise + gather forms),
    3 = + its 3x3 window form. Bit-identical results; measured not faster inside the step. Returns the old value. */
 int r3m_debug_set_pw16(int mode);
+/* Diagnostic (same-process A/B, tests): 1 (default) = the bf16 plans' 3x3 / stride-1 launches run the persistent kernel-row kernels of
+   csrc/conv_row16.hip; 0 = the per-tile halo kernels of csrc/conv_bf16.hip (rounds 3-5). The two accumulate the taps in different orders:
+   stored elements agree to 1 bf16 ulp, not bit for bit. Returns the old value. */
+int r3m_debug_set_conv3x3_bf16(int mode);
 /* Diagnostic, runs without a GPU: which kernel family the gather-GEMM dispatch (csrc/conv.hip gg_route) picks for every launch of one
    convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual
    join, 64 BatchNorm-backward partials, mask_bits = 1: their ReLU mask comes as bits) — nothing is launched. routes[i]: 1 = 3x3 window

@@ -8,7 +8,7 @@ OBJ="$HERE/../../build/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
-SRCS="conv conv_pw wgrad_win conv_bf16 conv_pw16 stem_bf16 bn loss adam lang augment engine capi"
+SRCS="conv conv_pw wgrad_win conv_bf16 conv_row16 conv_pw16 stem_bf16 bn loss adam lang augment engine capi"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
   stale=0

@@ -191,6 +191,7 @@ int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_
 }
 int r3m_debug_set_dynamic_tiles(int on) { return r3m::gg_set_dynamic_tiles(on); }
 int r3m_debug_set_pw16(int mode) { return r3m::pw16_set_mode(mode); }
+int r3m_debug_set_conv3x3_bf16(int mode) { return r3m::row16_set_mode(mode); }
 int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
                          int* routes, int cap) {
   R3M_REQUIRE(routes && cap >= 1, "debug_conv_route: routes buffer");

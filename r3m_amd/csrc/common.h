@@ -171,6 +171,10 @@ int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s)
 int pw16_form(const GatherGemmParams& p);               // 0 none, 1 pointwise, 2 gather, 3 gather with strided output rows
 int launch_pw16(const GatherGemmParams& p, hipStream_t s);
 int pw16_set_mode(int mode);                            // diagnostic (r3m_debug_set_pw16): 0 = per-tile kernels everywhere; returns the old value
+// conv_row16.hip (round 6): persistent kernel-row kernel of the 128-multiple-wide bf16 3x3 / stride-1 launches
+bool row16_eligible(const GatherGemmParams& p);
+int launch_conv3x3_row_bf16(const GatherGemmParams& p, hipStream_t s);
+int row16_set_mode(int mode);                           // diagnostic (r3m_debug_set_conv3x3_bf16): 0 = per-tile halo kernels; returns the old value
 int launch_transpose_w_bf16(const float* W, void* Wt, int Co, int T, int Ci, hipStream_t s);
 
 // ---- launchers (stem_bf16.hip): the stem on the bf16 MFMA, from a padded bf16 image of the normalised frames ----

@@ -564,6 +564,14 @@ int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   const bool ring = gg16_ring_min() > 0 && nk >= gg16_ring_min();
   const bool w8 = gg16_ring_min() < 0;       // experiment: 8 waves, 2 stages (2 blocks/CU = 16 waves/CU)
   int rc;
+  if (row16_eligible(p)) {                     // round 6: 128-multiple-wide 3x3 / stride-1 launches -> persistent kernel-row kernel (conv_row16.hip)
+    prof_begin(KC_GEMM_WIDE, flops, p.M, p.Nc, p.Ci, p.ntaps, s);
+    rc = launch_conv3x3_row_bf16(p, s);
+    prof_bytes(gather_gemm_alg_bytes(p, 2));
+    prof_end(s);
+    if (rc) return rc;
+    return check_launch("conv3x3_row_bf16");
+  }
   const int halo_rows = (gg16_halo() && halo_eligible(p) && pw16_form(p) != 3) ? halo_tile_rows(p) : 0;   // (3: the persistent window form takes it)
   if (halo_rows) {
     prof_begin(gg_wide(p.Nc) ? KC_GEMM_WIDE : KC_GEMM_NARROW, flops, p.M, p.Nc, p.Ci, p.ntaps, s);

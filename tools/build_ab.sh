@@ -13,7 +13,7 @@ build_tree() {   # $1 = source root holding r3m_amd/csrc + include, $2 = output 
   local src="$1" out="$2"; shift 2
   local obj; obj="$(mktemp -d)"
   local pids=()
-  for f in conv conv_pw wgrad_win conv_bf16 conv_pw16 stem_bf16 bn loss adam lang augment engine capi; do
+  for f in conv conv_pw wgrad_win conv_bf16 conv_row16 conv_pw16 stem_bf16 bn loss adam lang augment engine capi; do
     [ -f "$src/r3m_amd/csrc/$f.hip" ] || continue
     local extra=""; [ "$f" = conv_pw16 ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"
     $HIPCC $FLAGS $extra "$@" -c "$src/r3m_amd/csrc/$f.hip" -o "$obj/$f.o" & pids+=($!)
