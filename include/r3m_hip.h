@@ -34,9 +34,9 @@ int r3m_debug_occupancy(int* out4);   /* resident blocks/CU predicted for {gemm1
 int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_t stream);
 /* Diagnostic: 0 = the encoder's persistent-kernel launches assign tiles statically, 1 (default) = per-XCD tile queues. Returns the old value. */
 int r3m_debug_set_dynamic_tiles(int on);
-/* Diagnostic (same-process A/B): 0 (default) = the bf16 plans' forward / dgrad launches all run the per-tile kernels of
-   csrc/conv_bf16.hip; 1 = eligible launches run the persistent big-tile kernel of csrc/conv_pw16.hip (pointwise + gather forms),
-   3 = + its 3x3 window form. Bit-identical results; measured not faster inside the step. Returns the old value. */
+/* Diagnostic, PROBE BUILDS ONLY (-DR3M_PROBES; the shipped library does not contain the kernel and returns -1): 1 = eligible bf16
+   forward / dgrad launches run the round-5 persistent big-tile experiment csrc/conv_pw16.hip (pointwise + gather forms), 3 = + its
+   3x3 window form; 0 = off. Measured not faster inside the step. Returns the old value. */
 int r3m_debug_set_pw16(int mode);
 /* Diagnostic (same-process A/B, tests): 1 (default) = the bf16 plans' 3x3 / stride-1 launches run the persistent kernel-row kernels of
    csrc/conv_row16.hip; 0 = the per-tile halo kernels of csrc/conv_bf16.hip (rounds 3-5). The two accumulate the taps in different orders:
@@ -46,7 +46,8 @@ int r3m_debug_set_conv3x3_bf16(int mode);
    convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual
    join, 64 BatchNorm-backward partials, mask_bits = 1: their ReLU mask comes as bits) — nothing is launched. routes[i]: 1 = 3x3 window
    kernel, 11 / 12 / 13 = persistent kernel (pointwise / gather / strided-output form), 20 = 16-wide-K kernel, 21 = gather kernel,
-   22 = generic kernel, 30 = bf16 path. Returns the number of launches (a stride-2 dgrad has up to four), -1 on error. */
+   22 = generic kernel; bf16 launches: 30 = gather kernel, 31 = per-tile 3x3 halo kernel, 32 = persistent
+   kernel-row 3x3 kernel (csrc/conv_row16.hip). Returns the number of launches (a stride-2 dgrad has up to four), -1 on error. */
 int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
                          int* routes, int cap);
 void r3m_profile_enable(int on);

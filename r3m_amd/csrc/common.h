@@ -168,9 +168,16 @@ int launch_wgrad_bf16(const WgradParams& p, int splitK, hipStream_t s);
 int wgrad_bf16_pick_split(int M, int Co, int Ci, int T);
 int launch_convert_bf16(const float* src, void* dst, long long n, hipStream_t s);
 // conv_pw16.hip: persistent warp-specialised kernel of the bf16 plans (dense / parity-strided output rows)
+#ifdef R3M_PROBES
 int pw16_form(const GatherGemmParams& p);               // 0 none, 1 pointwise, 2 gather, 3 gather with strided output rows
 int launch_pw16(const GatherGemmParams& p, hipStream_t s);
 int pw16_set_mode(int mode);                            // diagnostic (r3m_debug_set_pw16): 0 = per-tile kernels everywhere; returns the old value
+#else                                                   // shipped library: the experiment is not compiled in
+static inline int pw16_form(const GatherGemmParams&) { return 0; }
+static inline int launch_pw16(const GatherGemmParams&, hipStream_t) { return 1; }
+static inline int pw16_set_mode(int) { return -1; }
+#endif
+int gg16_route(const GatherGemmParams& p);              // conv_bf16.hip: kernel family of a bf16 launch (r3m_debug_conv_route): 30 gather, 31 halo, 32 kernel-row, 33 probe-build persistent kernel
 // conv_row16.hip (round 6): persistent kernel-row kernel of the 128-multiple-wide bf16 3x3 / stride-1 launches
 bool row16_eligible(const GatherGemmParams& p);
 int launch_conv3x3_row_bf16(const GatherGemmParams& p, hipStream_t s);

@@ -981,7 +981,7 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     for (int t = 0; t < p.ntaps; ++t)
       p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
     if (t_route_out) {
-      if (t_route_n < t_route_cap) t_route_out[t_route_n] = GG_ROUTE_BF16;
+      if (t_route_n < t_route_cap) t_route_out[t_route_n] = gg16_route(p);    // 30 gather, 31 halo, 32 kernel-row (GG_ROUTE_BF16 + family)
       ++t_route_n;
       return 0;
     }

@@ -551,6 +551,14 @@ static int gg16_big() {
   return v;
 }
 
+// which kernel family launch_gather_gemm_bf16 runs (a pure function of the launch parameters; r3m_debug_conv_route reports it without a GPU)
+int gg16_route(const GatherGemmParams& p) {
+  if (row16_eligible(p)) return 32;
+  if (gg16_halo() && halo_eligible(p) && pw16_form(p) != 3 && halo_tile_rows(p)) return 31;
+  if (pw16_form(p)) return 33;
+  return 30;
+}
+
 int launch_gather_gemm_bf16(const GatherGemmParams& p, hipStream_t s) {
   R3M_REQUIRE(p.Ci % 64 == 0, "gather_gemm(bf16): Ci=%d must be a multiple of 64", p.Ci);
   R3M_REQUIRE(p.Nc % 4 == 0, "gather_gemm(bf16): Nc=%d must be a multiple of 4", p.Nc);

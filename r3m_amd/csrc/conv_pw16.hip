@@ -25,6 +25,9 @@
 #include "common.h"
 #include "conv_dev.h"
 
+// Round 6: an experiment record, not product code — compiled into probe builds (-DR3M_PROBES) only; the shipped
+// library gets the inline stubs of common.h and never routes here.
+#ifdef R3M_PROBES
 namespace r3m {
 
 typedef unsigned p16_u32x4 __attribute__((ext_vector_type(4)));
@@ -677,3 +680,4 @@ int launch_pw16(const GatherGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace r3m
+#endif  // R3M_PROBES

@@ -8,7 +8,7 @@ import ctypes as C
 
 import pytest
 
-WIN, PW_POINT, PW_GATHER, PW_STRIDED, BF16 = 1, 11, 12, 13, 30
+WIN, PW_POINT, PW_GATHER, PW_STRIDED, BF16, BF16_HALO, BF16_ROW = 1, 11, 12, 13, 30, 31, 32
 STATS, ACCUM, MASKED_ADD, BNRED = 1, 2, 4, 64
 
 
@@ -78,6 +78,28 @@ def test_fp32_convolutions_run_the_persistent_or_the_window_kernel(route, size, 
 
 def test_bf16_launches_take_the_bf16_path(route):
     assert route(1280, 56, 64, 256, 1, 1, 0, 0, STATS, 0, 1) == [BF16]
+
+
+@pytest.mark.parametrize("size,frames", [(50, 1280), (34, 2560), (18, 2560), (18, 8)])
+def test_bf16_3x3_stride1_launches_run_the_kernel_row_kernel(route, size, frames):
+    """Round 6 (csrc/conv_row16.hip): every 3x3 / stride-1 forward and input-gradient launch of the bf16 plans — whatever the frame
+    count, so that plans of different sizes accumulate in the same order — runs the persistent kernel-row kernel; everything else of
+    the bf16 path stays on the gather kernel (30). A shape that fell back to the per-tile halo kernel (31) would only show as lost
+    throughput and as a plan-size-dependent rounding."""
+    n = 0
+    for (name, H, Ci, Co, k, s, p, dflags, bits) in _layers(size):
+        fwd = route(frames, H, Ci, Co, k, s, p, 0, STATS, 0, 1)
+        want = [BF16_ROW] if (k == 3 and s == 1) else [BF16]
+        assert fwd == want, f"resnet{size} {name} forward -> {fwd}"
+        if name == "layer1.0.conv1" or name == "layer1.0.downsample":
+            continue
+        dg = route(frames, H, Ci, Co, k, s, p, 1, dflags, bits, 1)
+        if k == 3 and s == 1:
+            assert dg == [BF16_ROW], f"resnet{size} {name} dgrad (flags {dflags}) -> {dg}"
+            n += 1
+        else:
+            assert all(r == BF16 for r in dg), (name, dg)
+    assert n >= (12 if size == 50 else 7)
     assert route(1280, 56, 128, 128, 3, 2, 1, 1, BNRED, 0, 1) == [BF16] * 4
 
 

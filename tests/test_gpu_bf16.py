@@ -490,3 +490,83 @@ def test_stem_on_bf16_mfma(hip, Fr):
         assert hip.r3m_stem_conv_wgrad_bf16(xn16.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), ws.data_ptr(), wsb, Fr, acc, st()) == 0, hip.r3m_last_error()
         e_max, _ = rel_err(dwd.cpu().permute(0, 3, 1, 2).numpy(), (acc + 1) * wr.grad.numpy())
         assert e_max < 5e-5, (acc, e_max)
+
+
+# ---- round 6: the persistent kernel-row 3x3 kernel (csrc/conv_row16.hip) against the per-tile halo kernels it replaced ----------------
+# Different K order (32-channel chunk -> kernel row -> tap vs 64-channel chunk -> tap): the fp32 accumulators differ by round-off, the
+# stored bf16 elements by at most ONE ulp (of the element, floored at a quarter of the tensor's rms so that a cancelled sum is not
+# judged against its own tiny value), and each kernel is within half an ulp of float64 truth. Cases: both tile widths, M not a
+# multiple of 512, a tile that starts in front of the tensor, W = 56 / 30 (the widest windows), odd frame sizes.
+ROW16_CASES = [(5, 28, 128, 128), (3, 14, 256, 256), (9, 7, 512, 512), (40, 14, 128, 256), (2, 28, 64, 128), (1, 30, 128, 128),
+               (2, 56, 64, 64), (3, 28, 128, 64), (1, 9, 64, 64), (5, 56, 64, 64), (23, 7, 64, 384)]
+
+
+def _ulp_of(ref):
+    mag = torch.maximum(ref.abs(), 0.25 * ref.pow(2).mean().sqrt())
+    return torch.exp2(torch.floor(torch.log2(mag)) - 7)
+
+
+@pytest.mark.parametrize("case", ROW16_CASES, ids=lambda c: "N{}_H{}_{}to{}".format(*c))
+def test_conv3x3_kernel_row_kernel_vs_halo_kernel_and_float64(hip, case):
+    N, H, Ci, Co = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn((N, H, H, Ci), device=DEV, generator=g).bfloat16()
+    w = (torch.randn((Co, 3, 3, Ci), device=DEV, generator=g) * (1.5 / (9 * Ci) ** 0.5)).bfloat16()
+    dy = torch.randn((N, H, H, Co), device=DEV, generator=g).bfloat16()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).contiguous()
+    dref = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).contiguous()
+    rows = hip.r3m_conv2d_stats_rows(N, H, H, Co, 3, 1, 1)
+    wsb = hip.r3m_conv2d_dgrad_workspace_bytes(Ci, Co, 3)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=DEV)
+    wf = w.float()
+    buf = (__import__("ctypes").c_int * 4)()
+    assert hip.r3m_debug_conv_route(N, H, H, Ci, Co, 3, 1, 1, 0, 1, 0, 1, buf, 4) == 1 and buf[0] == 32, "not on the kernel-row route"
+    out = {}
+    old = hip.r3m_debug_set_conv3x3_bf16(1)
+    try:
+        for mode in (1, 0):
+            hip.r3m_debug_set_conv3x3_bf16(mode)
+            y = torch.full((N, H, H, Co), float("nan"), dtype=torch.bfloat16, device=DEV)
+            stats = torch.full((rows, 2, Co), float("nan"), device=DEV)
+            dx = torch.full((N, H, H, Ci), float("nan"), dtype=torch.bfloat16, device=DEV)
+            assert hip.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, 3, 1, 1, BF16, st()) == 0, hip.r3m_last_error()
+            assert hip.r3m_conv2d_dgrad_dt(dy.data_ptr(), wf.data_ptr(), dx.data_ptr(), ws.data_ptr(), wsb, N, H, H, Ci, Co, 3, 1, 1, BF16, st()) == 0, hip.r3m_last_error()
+            torch.cuda.synchronize()
+            out[mode] = (y, stats, dx)
+    finally:
+        hip.r3m_debug_set_conv3x3_bf16(old)
+    for name, new, base, truth in (("y", out[1][0], out[0][0], ref), ("dx", out[1][2], out[0][2], dref)):
+        ulp = _ulp_of(truth)
+        d = ((new.double() - base.double()).abs() / ulp).max().item()
+        e_new = ((new.double() - truth).abs() / ulp).max().item()
+        e_old = ((base.double() - truth).abs() / ulp).max().item()
+        assert torch.isfinite(new.float()).all()
+        assert d <= 1.0, f"{name}: kernel-row vs halo kernel {d} ulp"
+        assert e_new <= 0.51 and e_old <= 0.51, f"{name}: vs float64 {e_new} / {e_old} ulp"
+    # BatchNorm partials: the same rows (one per 128 result rows; per 256 for 64-wide outputs) from both kernels, fp32-level agreement
+    s1, s0 = out[1][1].double(), out[0][1].double()
+    assert torch.isfinite(s1).all() and s1.shape == s0.shape
+    assert (s1 - s0).abs().max().item() <= 3e-6 * s0.abs().max().item()
+    M = N * H * H
+    SR = 128 if Co % 128 == 0 else 256
+    s_ref = torch.stack([ref.reshape(M, Co)[r:r + SR].sum(0) for r in range(0, M, SR)])
+    q_ref = torch.stack([(ref.reshape(M, Co)[r:r + SR] ** 2).sum(0) for r in range(0, M, SR)])
+    assert ((s1[:, 0] - s_ref).abs().max() / s_ref.abs().max()).item() < 2e-6
+    assert ((s1[:, 1] - q_ref).abs().max() / q_ref.abs().max()).item() < 2e-6
+
+
+def test_conv3x3_kernel_row_kernel_rows_do_not_depend_on_the_frame_count(hip):
+    """Plans of different frame counts must produce the same rows (tests/test_gpu_fullsize.py compares a 2560-frame plan with
+    320-frame ones): the kernel-row kernel's accumulation order is a property of the layer, not of M."""
+    H, Ci, Co = 14, 256, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((700, H, H, Ci), device=DEV, generator=g).bfloat16()
+    w = (torch.randn((Co, 3, 3, Ci), device=DEV, generator=g) * 0.03).bfloat16()
+    ys = []
+    for N in (700, 3):
+        y = torch.empty((N, H, H, Co), dtype=torch.bfloat16, device=DEV)
+        stats = torch.empty((hip.r3m_conv2d_stats_rows(N, H, H, Co, 3, 1, 1), 2, Co), device=DEV)
+        assert hip.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, 3, 1, 1, BF16, st()) == 0, hip.r3m_last_error()
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0][:3].view(torch.int16), ys[1].view(torch.int16))

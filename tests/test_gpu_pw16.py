@@ -24,15 +24,22 @@ def st():
 
 @pytest.fixture()
 def restore_mode(hip):
+    """Round 6: the experiment is compiled into probe builds only (tools/build_ab.sh none probes; R3M_HIP_LIB=...) — the shipped library
+    answers -1 and these tests skip. The comparison partner is the per-tile family: the 3x3 launches are pinned to the halo kernels."""
     old = hip.r3m_debug_set_pw16(0)
+    if old == -1:
+        pytest.skip("csrc/conv_pw16.hip is not in the shipped library (probe builds only)")
+    old3 = hip.r3m_debug_set_conv3x3_bf16(0)
     yield
     hip.r3m_debug_set_pw16(old)
+    hip.r3m_debug_set_conv3x3_bf16(old3)
 
 
-def test_default_route_is_the_per_tile_family(hip):
+def test_shipped_library_does_not_contain_the_experiment_or_has_it_off(hip):
     old = hip.r3m_debug_set_pw16(0)
-    hip.r3m_debug_set_pw16(old)
-    assert old == 0, "the persistent bf16 kernel is an opt-in experiment (DESIGN.md §9): the shipped default must stay 0"
+    if old != -1:
+        hip.r3m_debug_set_pw16(old)
+    assert old in (-1, 0), "the persistent bf16 kernel is an opt-in experiment (DESIGN.md §9): never on by default"
 
 
 @pytest.mark.parametrize("mode", [1, 3], ids=["pointwise+gather", "+window"])

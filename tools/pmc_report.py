@@ -76,6 +76,9 @@ def group(k):
     k = re.sub(r"conv3x3_win_kernel<128, 128, 2, 2, \d+, \d+>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"conv3x3_halo_bf16_kernel<(128|256), 128, 2, 2, \d+>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"conv3x3_halo_bf16_kernel<256, 64, 4, 1, \d+>", "gather_gemm 256x64 (all epilogues)", k)
+    # round 6: the persistent kernel-row 3x3 kernel (conv_row16.hip): <BN, EPI>
+    k = re.sub(r"conv3x3_row_bf16_kernel<128, \d+>", "gather_gemm 128x128 (all epilogues)", k)
+    k = re.sub(r"conv3x3_row_bf16_kernel<64, \d+>", "gather_gemm 256x64 (all epilogues)", k)
     # round 5: the persistent big-tile bf16 kernel (conv_pw16.hip): wide outputs / 64-channel outputs
     k = re.sub(r"pw16_gemm_kernel<256, (128|256), \d+, \d+(, \d+)*>", "gather_gemm 128x128 (all epilogues)", k)
     k = re.sub(r"pw16_gemm_kernel<(256|512), 64, \d+, \d+(, \d+)*>", "gather_gemm 256x64 (all epilogues)", k)
