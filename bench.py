@@ -458,6 +458,9 @@ SECONDARY = [   # the other single-node BASELINE configs, timed AFTER the headli
     ("configs[2]", dict(size=50, clips=256, precision="bf16", langweight=1.0, doaug="none")),
     ("configs[3]", dict(size=50, clips=256, precision="fp32", langweight=1.0, doaug="none")),
     ("configs[4]", dict(size=34, clips=512, precision="bf16", langweight=0.0, doaug="rctraj")),
+    # the literal reading of BASELINE.json's "bs=256/GPU": 256 FRAMES through the encoder alone, forward + backward + Adam (SURVEY.md §8(d)
+    # continuity point; the headline reads it as 256 clips = 1280 frames, the batch `Trainer.update` sees at batch_size 256)
+    ("encoder_only_256_frames", dict(size=50, clips=256, precision="fp32", langweight=0.0, doaug="none", encoder_only_frames=256)),
 ]
 
 
@@ -516,7 +519,7 @@ def main():
     if is_headline(args) and not args.no_secondary and args.secondary_steps > 0:
         sec = {}
         for name, sw in SECONDARY:
-            sw = dict(sw, unfused_crop=False, encoder_only_frames=0)
+            sw = dict({"encoder_only_frames": 0}, **sw, unfused_crop=False)
             try:
                 r = measure(sw, args.secondary_steps, args.secondary_warmup, min(args.prewarm_seconds, 2.0), ctx)
             except Exception as e:   # a secondary workload must never cost the headline its line
@@ -532,23 +535,12 @@ def main():
                 sec[name] = r
         if rank == 0:
             out["secondary"] = sec
-        # what the measurement aid costs: the timed steps above bracket every conv GEMM launch with HIP events (r3m_profile_enable);
-        # one short leg of the same workload without them, after everything else
-        if not args.no_kernel_timing:
-            try:
-                r0 = measure(w, min(args.steps, 10), 3, min(args.prewarm_seconds, 1.0), ctx, kernel_timing=False)
-            except Exception as e:
-                if use_dist:
-                    raise
-                r0 = {"error": f"{type(e).__name__}: {e}"}
-            if rank == 0:
-                if "error" in r0:
-                    out["kernel_timing_overhead_ms"] = None
-                else:
-                    out["ms_per_step_without_kernel_timing"] = r0["ms_per_step"]
-                    out["kernel_timing_overhead_ms"] = round(out["ms_per_step"] - r0["ms_per_step"], 3)
-                    out["kernel_timing_overhead_note"] = ("difference of two legs run a minute apart on a power-limited part: good to about "
-                                                          "+-1 ms; the interleaved same-box A/B reads 0.3 ms (profiles/r05_event_fence_ab.txt)")
+        # (rounds 4-5 printed `kernel_timing_overhead_ms` from a second short leg here: a difference of two legs run a minute apart on a
+        # power-limited part is good to +-1 ms — it read -1.85 ms in BENCH_r05 — so it is gone. What the brackets
+        # cost was measured once with interleaved same-box legs: 0.3 ms per step, profiles/r05_event_fence_ab.txt.)
+        if rank == 0 and not args.no_kernel_timing:
+            out["kernel_timing_note"] = ("timed steps bracket the dominant kernel class only (fence-free HIP events, 99 launches): "
+                                         "0.3 ms per step in the interleaved same-box A/B profiles/r05_event_fence_ab.txt")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if affinity0 is not None:

@@ -54,7 +54,6 @@ class _EncoderFn(torch.autograd.Function):
         h = module._run_forward(x, training, crop, saved=True)
         ctx.module = module
         ctx.slot, ctx.generation = module._last_forward
-        module._awaiting += 1            # forwards whose backward has not run yet (max_live_forwards > 1: several per step)
         if 0 <= ctx.slot < len(module._ring):
             # the slot stays "live" while this graph node exists and has not run its backward: forwards that need no backward
             # (no_grad / eval calls between a training forward and its backward) must not take it (_pick_slot)
@@ -64,12 +63,14 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         m = ctx.module
-        m._awaiting = max(0, m._awaiting - 1)
         # The data-parallel stage hook starts an ASYNC all-reduce on a slice of the flat gradient buffer. With several live forwards
         # ((h1 + h2).backward()) every backward accumulates into the same buffer, so only the LAST outstanding one may fire it: an
-        # earlier one would hand RCCL a slice the next backward is still adding to. (A forward whose graph is dropped never
-        # decrements: the hook then never fires and finish_gradient_sync reduces the whole buffer itself.)
-        m._run_backward(dh.contiguous(), ctx.generation, ctx.slot, fire_hooks=m._awaiting == 0)
+        # earlier one would hand RCCL a slice the next backward is still adding to. "Outstanding" = ring slots whose autograd node is
+        # still alive and has not run (weak references: a forward whose graph was dropped — an eval call without no_grad, an
+        # exception before backward — stops counting when its node is collected; round 5 kept a manual counter that such a forward
+        # left raised for good, silently costing every later step its comm / compute overlap: ADVICE r5).
+        others = sum(1 for sl in m._ring if sl.live and sl.waiting() is not ctx)
+        m._run_backward(dh.contiguous(), ctx.generation, ctx.slot, fire_hooks=others == 0)
         if 0 <= ctx.slot < len(m._ring):
             w = m._ring[ctx.slot].waiting
             if w is not None and w() is ctx:
@@ -164,7 +165,6 @@ class HipResNet(nn.Module):
         self.fc = nn.Identity()   # models_r3m.py:62
         self._flat_p, self._flat_b, self._flat_nbt = flat_p, flat_b, flat_nbt
         self._flat_g = None
-        self._awaiting = 0      # forwards through autograd whose backward has not run yet (see _EncoderFn.backward)
         self._ring = [_LiveSlot() for _ in range(self.max_live_forwards)]   # _plans / _arena below are slot 0's
         self._ring_pos = 0
         self._scratch = None          # _LiveSlot for forwards without a backward while every ring slot is live (_pick_slot)
@@ -226,6 +226,11 @@ class HipResNet(nn.Module):
                 else:
                     t.zero_()
             self._flat_nbt.zero_()
+
+    @property
+    def _awaiting(self):
+        """forwards through autograd whose backward has not run yet (see _EncoderFn.backward)"""
+        return sum(1 for sl in self._ring if sl.live)
 
     # ---- flat storage ----------------------------------------------------------------------------------------
     def _is_flat(self):
@@ -350,7 +355,7 @@ class HipResNet(nn.Module):
         reference R3M deep-copies cleanly (plain nn.Module), so must this."""
         st = self.__dict__.copy()
         st.update(_ring=[_LiveSlot() for _ in self._ring], _ring_pos=0, _scratch=None, _last_forward=(0, 0), _flat_g=None,
-                  _stage_hook=None, _grad_fresh=True, _awaiting=0)
+                  _stage_hook=None, _grad_fresh=True)
         return st
 
     def __setstate__(self, st):

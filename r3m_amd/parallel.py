@@ -126,7 +126,9 @@ class SingleDevice(nn.Module):
 class ReplicatedInference(nn.Module):
     """Opt-in multi-GPU INFERENCE for `load_r3m` users: the reference returns `DataParallel(rep)`, which splits an inference batch
     over all visible GPUs and gathers the embeddings on GPU 0 (/root/reference/r3m/__init__.py:72). Here: one replica of the module
-    per device (deep copies, refreshed whenever the wrapped module's parameters or buffers change), the batch split along dim 0 in
+    per device (deep copies, rebuilt when the wrapped module's storage changes and re-filled with its current VALUES on every forward:
+    three flat device-to-device copies for the encoder — optimizer steps and BatchNorm statistics updates happen in native kernels that
+    no version counter sees), the batch split along dim 0 in
     device order, every chunk enqueued on its own device's stream (the chunks run concurrently), outputs concatenated on the first
     device. `.module` and the state-dict key set are those of SingleDevice. Forward only: training is DistributedR3M's job (one
     process per GPU) and a backward through this wrapper raises.
@@ -143,22 +145,64 @@ class ReplicatedInference(nn.Module):
         self._replicas = None      # plain list on purpose: replicas are not sub-modules (not in state_dict(), not moved by .to())
         self._stamp = None
 
-    def _state_stamp(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.module.parameters()) + list(self.module.buffers()))
+    def _structure_stamp(self):
+        """What a replica's STRUCTURE depends on: which tensors the module holds (a load_state_dict with assign, .to(), a re-flatten
+        give new storage) and train / eval mode. The VALUES are not part of it: the framework's own updates — FusedAdam / FusedSGD
+        steps, the train-mode BatchNorm running-statistics update — write the flat buffers through raw pointers in native kernels and
+        never bump `tensor._version`, so values are re-broadcast on every forward instead (`_refresh`)."""
+        return tuple(t.data_ptr() for t in list(self.module.parameters()) + list(self.module.buffers()))
+
+    @staticmethod
+    def _flat_sets(mod):
+        """[(sub-module path, [flat tensors])] for every sub-module that keeps its state in flat buffers (HipResNet: parameters, BatchNorm
+        buffers, batch counters; the language-reward head: parameters) + the ids of all tensors those buffers cover."""
+        sets, covered = [], set()
+        for name, m in mod.named_modules():
+            fl = []
+            if hasattr(m, "_flat_p") and callable(getattr(m, "flat_params", None)):
+                fl.append(m.flat_params())
+                for attr in ("_flat_b", "_flat_nbt"):
+                    if isinstance(getattr(m, attr, None), torch.Tensor):
+                        fl.append(getattr(m, attr))
+                covered.update(id(t) for t in list(m.parameters(recurse=True)) + list(m.buffers(recurse=True)))
+                sets.append((name, fl))
+        return sets, covered
+
+    def _refresh(self, rep, dev):
+        """Copy the live module's values into a replica: one device-to-device copy per flat buffer (three for the encoder, one for the
+        language head), tensor by tensor for whatever is not flat. Cheap next to a forward, and correct whatever wrote the values."""
+        src_sets, covered = self._flat_sets(self.module)
+        dst_sets, _ = self._flat_sets(rep)
+        with torch.no_grad():
+            for (n0, fs), (n1, fd) in zip(src_sets, dst_sets):
+                assert n0 == n1 and len(fs) == len(fd)
+                for a, b in zip(fs, fd):
+                    b.copy_(a, non_blocking=True)
+            for a, b in zip(list(self.module.parameters()) + list(self.module.buffers()), list(rep.parameters()) + list(rep.buffers())):
+                if id(a) not in covered:
+                    b.copy_(a, non_blocking=True)
 
     def _ensure_replicas(self):
-        stamp = self._state_stamp()
-        if self._replicas is not None and stamp == self._stamp:
-            return
-        import copy
+        stamp = self._structure_stamp()
         first = next(self.module.parameters()).device
-        self._replicas = []
-        for i, d in enumerate(self.devices):
-            if i == 0 and d == first:
-                self._replicas.append(self.module)
-            else:
-                self._replicas.append(copy.deepcopy(self.module).to(d).train(self.module.training))
-        self._stamp = stamp
+        if self._replicas is None or stamp != self._stamp:
+            import copy
+            self._replicas = []
+            for i, d in enumerate(self.devices):
+                if i == 0 and d == first:
+                    self._replicas.append(self.module)
+                else:
+                    self._replicas.append(copy.deepcopy(self.module).to(d).train(self.module.training))
+            self._stamp = stamp
+            return
+        src_stream_dev = first
+        for rep, d in zip(self._replicas, self.devices):
+            if rep is not self.module:
+                import contextlib
+                with (torch.cuda.device(src_stream_dev) if src_stream_dev.type == "cuda" else contextlib.nullcontext()):
+                    self._refresh(rep, d)
+        if first.type == "cuda" and any(d != first for d in self.devices):
+            torch.cuda.current_stream(first).synchronize()     # the copies were enqueued on the source device's stream
 
     def finish_gradient_sync(self):
         pass
@@ -170,9 +214,10 @@ class ReplicatedInference(nn.Module):
         self._ensure_replicas()
         chunks = [c for c in torch.chunk(x, len(self.devices), dim=0) if c.shape[0] > 0]
         outs = []
+        import contextlib
         for rep, dev, c in zip(self._replicas, self.devices, chunks):
             rep.train(self.module.training)
-            with torch.cuda.device(dev):
+            with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
                 outs.append(rep(c.to(dev, non_blocking=True), *a, **k))
         first = self.devices[0]
         return torch.cat([o.to(first, non_blocking=True) for o in outs], 0)
@@ -273,8 +318,8 @@ class DistributedR3M(nn.Module):
     def check_replicas(self, raise_on_mismatch=True):
         """Are the replicas still identical? Every rank applies the same averaged gradients to the same parameters, so the flat
         parameter buffers must stay BIT-identical across ranks; nothing re-checks that after construction unless this is called
-        (the training loop does at every snapshot). Compares a float64 (sum, sum of squares) stamp of each owner's parameters with
-        two small all-reduces (MIN, MAX); BatchNorm running statistics differ by design (per-rank statistics, as the reference's
+        (the training loop does at every snapshot). Compares an exact integer stamp (two wrapping int64 sums over the fp32 words) of each owner's parameters with
+        two small all-reduces (MIN, MAX); non-finite values raise FloatingPointError instead of a divergence report; BatchNorm running statistics differ by design (per-rank statistics, as the reference's
         DataParallel normalises per replica chunk; snapshots carry rank 0's) and are only reported. Returns
         {"params_identical": bool, "param_spread": max |max - min| / (|max| + tiny), "bn_buffer_spread": same for the buffers}."""
         out = {"params_identical": True, "param_spread": 0.0, "bn_buffer_spread": 0.0}
@@ -282,12 +327,39 @@ class DistributedR3M(nn.Module):
             return out
 
         def spread(t):
-            d = t.detach().double()
-            stamp = torch.stack([d.sum(), (d * d).sum()])
+            """Bit-exact replica comparison without a float64 copy: the fp32 words are reinterpreted as int32 and stamped with two
+            wrapping int64 sums (plain and position-weighted: a permutation or a compensating pair of changes moves the second).
+            MIN / MAX all-reduce of the stamp: equal on every rank <=> the same bits everywhere (up to a 2^-64-ish collision).
+            Non-finite values are detected first and reported as such — NaN != NaN would otherwise read as 'diverged'."""
+            d = t.detach()
+            finite = torch.isfinite(d).all().to(torch.int64).reshape(1)
+            dist.all_reduce(finite, op=dist.ReduceOp.MIN, group=self.sync.group)
+            if int(finite.item()) == 0:
+                raise FloatingPointError("r3m_amd.DistributedR3M.check_replicas: non-finite parameter or buffer values on at least one rank "
+                                         "(a loss blow-up, not a replica divergence)")
+            w = d.contiguous().view(torch.int32).to(torch.int64)
+            n = w.numel()
+            CH = 1 << 22
+            s1 = torch.zeros((), dtype=torch.int64, device=d.device)
+            s2 = torch.zeros((), dtype=torch.int64, device=d.device)
+            for o in range(0, n, CH):                                  # chunked: the int64 image of a chunk is 32 MB, not 8 bytes per weight
+                c = w[o:o + CH]
+                s1 += c.sum()
+                s2 += (c * (torch.arange(o, o + c.numel(), device=d.device, dtype=torch.int64) % 65521 + 1)).sum()
+            stamp = torch.stack([s1, s2])
             lo, hi = stamp.clone(), stamp.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.sync.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.sync.group)
-            return float(((hi - lo).abs() / (hi.abs() + 1e-300)).max()), bool(torch.equal(lo, hi))
+            same = bool(torch.equal(lo, hi))
+            if same:
+                return 0.0, True
+            # diverged: say by how much (float view of the values; costs a reduction, only on the failure path)
+            v = d.double()
+            fs = torch.stack([v.sum(), (v * v).sum()])
+            flo, fhi = fs.clone(), fs.clone()
+            dist.all_reduce(flo, op=dist.ReduceOp.MIN, group=self.sync.group)
+            dist.all_reduce(fhi, op=dist.ReduceOp.MAX, group=self.sync.group)
+            return float(((fhi - flo).abs() / (fhi.abs() + 1e-300)).max()), False
 
         for owner in self._owners():
             sp, same = spread(owner.flat_params())
@@ -311,7 +383,12 @@ class DistributedR3M(nn.Module):
             # backpropagated): reduce the whole buffer now — correct, just not overlapped
             g = conv.flat_grads()
             self.sync.reduce_slice(g, 0, g.numel())
-            conv._awaiting = 0
+            if not getattr(self, "_warned_unoverlapped", False):
+                self._warned_unoverlapped = True
+                import warnings
+                warnings.warn("r3m_amd.DistributedR3M: the encoder gradients of this step were all-reduced in one blocking piece after "
+                              "backward (a live forward was never backpropagated, so no backward could start the overlapped slices); "
+                              "results are correct, the comm / compute overlap is lost for such steps", RuntimeWarning)
         self.sync.finish()
         self._head_done = False
         self._enc_sent = False

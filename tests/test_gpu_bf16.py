@@ -427,6 +427,101 @@ def test_encoder_bf16_well_conditioned_absolute(hip, size):
         assert 0.97 <= ratio <= 1.03, ratio
 
 
+AUTOCAST_DRAWS = [("w", "smooth"), ("wb", "smoothb"), ("wc", "smoothc")]     # (weight tag, frame tag) of oracle/detgen.py
+
+
+def _last_bn_name(size):
+    return "layer4.2.bn3" if size == 50 else ("layer4.2.bn2" if size == 34 else "layer4.1.bn2")
+
+
+@pytest.mark.parametrize("size", [18, 50])
+def test_encoder_bf16_against_torch_cpu_autocast_witness(hip, size):
+    """an INDEPENDENT witness for the mixed-precision path. `oracle/bf16_emul.py` is this repository's own model of
+    where the engine rounds; torch's own `torch.autocast("cpu", dtype=torch.bfloat16)` around the pinned oracle encoder (the graph
+    behind /root/reference/r3m/models/models_r3m.py:96-99, fp32 master weights) is somebody else's. On the well-conditioned case
+    (small residual branches, low-frequency frames — the case in which bf16 arithmetic is meaningful at all, see the test above),
+    train-mode BatchNorm, three (weights, frames) draws, everything is measured against float64 truth of the same fp32 masters:
+        err(X) = ||X - float64|| / ||float64||   for the embedding and seven named gradient tensors,
+    and gated G8-style: the MEDIAN over the draws of err(HIP bf16) / err(torch autocast) must be <= 2 and every draw <= 4 — the HIP
+    path may not be meaningfully worse than what `torch.autocast(bfloat16)` around the reference's encoder does on a CPU. The same
+    three-way table is printed (and gated) for the emulation, so the checker of every other bf16 test is itself checked against torch.
+    Where the two differ by construction: autocast keeps BatchNorm outputs, the residual sum and the pooled
+    embedding in bf16 and takes batch statistics from bf16-rounded conv outputs; the engine takes them from the fp32 accumulators,
+    keeps the embedding fp32, and rounds each stored tensor once."""
+    from oracle import bf16_emul, detgen, resnet_ref
+    from r3m_amd import R3M
+    N = 4 if size == 50 else 8
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    lb = _last_bn_name(size)
+    names = ["conv1.weight", "bn1.weight", "bn1.bias", lb + ".weight", lb + ".bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight"]
+
+    def enc(m, v):
+        z = m.maxpool(m.relu(m.bn1(m.conv1(v))))
+        return m.layer4(m.layer3(m.layer2(m.layer1(z)))).mean((2, 3))
+
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+    rows = {k: {"hip": [], "emul": []} for k in ["h"] + names}
+    for draw, (wtag, ftag) in enumerate(AUTOCAST_DRAWS):
+        ref0 = getattr(resnet_ref, f"resnet{size}")()
+        shapes = [(k, tuple(v.shape)) for k, v in ref0.state_dict().items() if not k.startswith("fc.")]
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in detgen.resnet_state_dict_small_residual(shapes, size, 0.1, tag=wtag).items()}
+        x = torch.from_numpy(detgen.smooth_frames(ftag, (N, 3, 224, 224), 7))
+        cw = None
+
+        def run_cpu(dtype, mode):
+            nonlocal cw
+            m = getattr(resnet_ref, f"resnet{size}")().to(dtype)
+            m.load_state_dict({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}, strict=False)
+            m.train(True)
+            xn = (x.to(dtype) / 255.0 - mean.to(dtype)) / std.to(dtype)
+            if mode == "autocast":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    h = enc(m, xn)
+                assert h.dtype == torch.bfloat16, "torch.autocast did not run the encoder in bfloat16"
+                h = h.float()
+            elif mode == "emul":
+                h = bf16_emul.forward_bf16(m, xn)
+            else:
+                h = enc(m, xn)
+            if cw is None:
+                cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5))
+            (h * cw.to(h.dtype)).sum().backward()
+            return h.detach().double(), {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+
+        h64, g64 = run_cpu(torch.float64, "exact")
+        hac, gac = run_cpu(torch.float32, "autocast")
+        hem, gem = run_cpu(torch.float64, "emul")
+        m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0, precision="bf16")
+        m.convnet.load_state_dict(sd)
+        m = m.to(DEV)
+        m.train(True)
+        h = m(x.to(DEV))
+        (h * cw.to(DEV)).sum().backward()
+        ghip = {k: p.grad.detach().cpu().double() for k, p in m.convnet.named_parameters()}
+        hhip = h.detach().cpu().double()
+        assert torch.isfinite(hhip).all() and all(torch.isfinite(v).all() for v in ghip.values())
+        for k in ["h"] + names:
+            t64, tac, tem, thip = (h64, hac, hem, hhip) if k == "h" else (g64[k], gac[k], gem[k], ghip[k])
+            e_ac, e_em, e_hip = l2(tac, t64), l2(tem, t64), l2(thip, t64)
+            rows[k]["hip"].append(e_hip / max(e_ac, 1e-12))
+            rows[k]["emul"].append(e_em / max(e_ac, 1e-12))
+            _report(f"r{size} bf16 AUTOCAST WITNESS draw {draw} {k}: l2-rel vs float64: torch-autocast {e_ac:.3e}  hip-bf16 {e_hip:.3e}  "
+                    f"emulation {e_em:.3e}  (hip/autocast {e_hip / max(e_ac, 1e-12):.2f}, emulation/autocast {e_em / max(e_ac, 1e-12):.2f})")
+        del m
+    fails = []
+    for k, r in rows.items():
+        for who in ("hip", "emul"):
+            med = sorted(r[who])[1]
+            _report(f"r{size} bf16 AUTOCAST WITNESS {k}: {who} / torch-autocast error ratios over the three draws "
+                    f"{', '.join(f'{v:.2f}' for v in r[who])}  median {med:.2f}")
+            if med > 2.0 or max(r[who]) > 4.0:
+                fails.append((k, who, r[who]))
+    assert not fails, fails
+
+
 def test_train_steps_bf16_track_fp32(hip):
     """a few full Trainer.update steps with the bf16 encoder (TCN + LP loss, fused Adam on fp32 masters): finite metrics and
     the loss follows the fp32 run step by step (same data, same permutations)"""

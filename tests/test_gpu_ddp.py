@@ -591,6 +591,20 @@ def test_replicated_inference_split_gather(hip):
         out2 = rep(x)
     assert not torch.allclose(ref2, ref)
     torch.testing.assert_close(out2, ref2, rtol=2e-5, atol=1e-6)
+    # the framework's OWN updates write the flat buffers through raw pointers in native kernels — a FusedAdam step and the
+    # running-statistics update of a train-mode forward bump no tensor version. The replicas must still follow.
+    m.train()
+    m.encoder_opt.zero_grad()
+    m(x).sum().backward()
+    m.encoder_opt.step()
+    m.eval()
+    with torch.no_grad():
+        ref3 = SingleDevice(m)(x)
+        out3 = rep(x)
+    assert not torch.allclose(ref3, ref2)
+    torch.testing.assert_close(out3, ref3, rtol=2e-5, atol=1e-6)
+    assert torch.equal(rep._replicas[2].convnet.flat_params(), m.convnet.flat_params())
+    assert torch.equal(rep._replicas[1].convnet._flat_b, m.convnet._flat_b)
     with pytest.raises(RuntimeError, match="forward-only"):
         rep(x)                                                       # grad mode: training goes through DistributedR3M
     with torch.no_grad():                                            # fewer frames than devices: empty chunks are skipped

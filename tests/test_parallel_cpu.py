@@ -1,8 +1,11 @@
-"""not gpu: the N>1 path with world_size 2 on the gloo backend — gradient slices of a flat buffer are mean-reduced in the
-order the encoder backward finishes its stages, parameters/buffers start identical on every rank."""
+"""not gpu: the N>1 path with world sizes 2, 4 and 8 on the gloo backend — gradient slices of a flat buffer are mean-reduced in the
+order the encoder backward finishes its stages, parameters/buffers start identical on every rank. Round 6: the
+rank-indexed code (gather row offsets, global-negatives row ownership, slice merge, replica check, CPU-affinity slices,
+ReplicatedInference chunking) had never seen a rank >= 2; every test here now runs at world 2, 4 and 8."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -138,7 +141,9 @@ def _worker(rank, world, port, q):
         fired = []
 
         def fake_forward(x, training, crop=None, saved=False):
-            conv._last_forward = (0, 0)
+            from r3m_amd.encoder import _pick_slot
+            slot, conv._ring_pos = _pick_slot([sl.live for sl in conv._ring], conv._ring_pos, saved)     # as the real forward does
+            conv._last_forward = (slot, 0)
             return torch.ones((x.shape[0], conv.outdim))
 
         def fake_backward(dh, generation, si=0, fire_hooks=True):
@@ -168,7 +173,9 @@ def _worker(rank, world, port, q):
             assert net3.sync.launched == before + 2                           # ResNet-18: two slices, each sent ONCE
             g3 = conv.flat_grads()
             assert torch.allclose(g3, torch.full_like(g3, 2.0 * sum(range(1, world + 1)) / world)), float(g3[0])
-        # a forward whose graph is dropped keeps the count up: no backward fires the hooks, finish() reduces the whole buffer itself
+        # a forward whose graph is still alive when the other's backward runs: that backward may not fire the hooks, finish() reduces
+        # the whole buffer itself (and says so once); when the graph is dropped the count falls back by itself
+        import warnings
         m3.encoder_opt.zero_grad()
         h1 = _EncoderFn.apply(x, anchor, conv, True, None)
         h2 = _EncoderFn.apply(x, anchor, conv, True, None)
@@ -176,9 +183,22 @@ def _worker(rank, world, port, q):
         before = net3.sync.launched
         h2.sum().backward()
         del h1
-        assert fired == [False]
-        net3.finish_gradient_sync()
+        assert fired == [False] and conv._awaiting == 0
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            net3.finish_gradient_sync()
+        assert any("overlap is lost" in str(c.message) for c in caught)
         assert net3.sync.launched == before + 1 and conv._awaiting == 0
+        # ... and the NEXT step overlaps again: a dropped forward leaves nothing behind
+        m3.encoder_opt.zero_grad()
+        hd = _EncoderFn.apply(x, anchor, conv, True, None)       # a grad-enabled forward nobody differentiates
+        del hd
+        h1 = _EncoderFn.apply(x, anchor, conv, True, None)
+        fired.clear()
+        h1.sum().backward()
+        assert fired == [True]
+        net3.finish_gradient_sync()
+        m3.encoder_opt.zero_grad()
         g3 = conv.flat_grads()
         assert torch.allclose(g3, torch.full_like(g3, sum(range(1, world + 1)) / world))
         # two SEPARATE backward() calls in one step: the second would add into slices that are being reduced — refused
@@ -209,8 +229,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gradient_sync_world2_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gradient_sync_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -226,7 +246,7 @@ def test_gradient_sync_world2_gloo():
 
 def _gneg_worker(rank, world, port, q):
     """global_negatives (/root/reference/r3m/trainer.py:41,87,136 — DataParallel gathers the embeddings and GPU 0
-    draws negatives from the WHOLE batch): 2 ranks x B/2 clips, embeddings gathered, the oracle's objective evaluated on the gathered
+    draws negatives from the WHOLE batch): `world` ranks x B/world clips, embeddings gathered, the oracle's objective evaluated on the gathered
     batch by every rank with rank 0's permutations, each rank backpropagating its own rows."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -237,12 +257,12 @@ def _gneg_worker(rank, world, port, q):
         from oracle import r3m_ref
         from r3m_amd import R3M
         from r3m_amd.parallel import DistributedR3M
-        B, D, Fin = 6, 32, 20                             # global batch of 6 clips; "encoder" = one linear map R^20 -> R^32
+        B, D, Fin = (6 if world == 2 else 8), 32, 20      # global batch of 6 (8) clips; "encoder" = one linear map R^20 -> R^32
         g = torch.Generator().manual_seed(5)
         X = torch.randn((B, 5, Fin), generator=g)
         theta0 = torch.randn((Fin, D), generator=g) * 0.3
         feats = torch.randn((B, 768), generator=g) * 0.3
-        mask = torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0, 1.0])
+        mask = torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0, 1.0, 0.0, 1.0][:B])
         tcn_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(6)])
         lang_perm = torch.stack([torch.randperm(B, generator=g) for _ in range(9)])
         ref = r3m_ref.R3MRef(size=18, hidden_dim=16, l2weight=1e-2, l1weight=1e-2, langweight=1.0, tcnweight=1.0)
@@ -297,8 +317,8 @@ def _gneg_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_global_negatives_world2_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_global_negatives_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -310,3 +330,38 @@ def test_global_negatives_world2_gloo():
         p.join(timeout=60)
     for rank, status in res:
         assert status == "ok", f"rank {rank}: {status}"
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 5, 8])
+def test_replicated_inference_chunking_with_a_fake_device_list(ndev):
+    """parallel.ReplicatedInference (what `load_r3m(..., replicate=True)` returns on a multi-GPU host) on `ndev` stand-in devices — the
+    CPU named `ndev` times: the batch splits into per-device chunks in device order, every replica but the first is a deep copy, the
+    outputs come back concatenated in order, batches smaller than the device count skip the empty chunks, and a value change of the
+    wrapped module that NO version counter sees (the framework's native kernels write parameters through raw pointers: ADVICE r5)
+    reaches every replica before the next forward."""
+    from r3m_amd.parallel import ReplicatedInference
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.BatchNorm1d(4)).eval()
+    rep = ReplicatedInference(m, devices=["cpu"] * ndev)
+    for n in (1, ndev - 1, ndev, ndev + 1, 3 * ndev + 2):
+        x = torch.randn((n, 6))
+        with torch.no_grad():
+            out = rep(x)
+            torch.testing.assert_close(out, m(x), rtol=1e-6, atol=1e-6)      # (a CPU GEMM rounds by batch size: not bit for bit)
+    assert len(rep._replicas) == ndev and rep._replicas[0] is m and all(r is not m for r in rep._replicas[1:])
+    # a raw-pointer write: same storage, same version counter, new values
+    w = m[0].weight
+    v0 = w._version
+    import ctypes
+    src_w, rm = torch.ones_like(w) * 0.25, m[1].running_mean
+    src_rm = torch.ones_like(rm) * 2.0
+    ctypes.memmove(w.data_ptr(), src_w.data_ptr(), w.numel() * 4)
+    ctypes.memmove(rm.data_ptr(), src_rm.data_ptr(), rm.numel() * 4)
+    assert w._version == v0 and float(w[0, 0]) == 0.25
+    x = torch.randn((2 * ndev + 1, 6))
+    with torch.no_grad():
+        torch.testing.assert_close(rep(x), m(x), rtol=1e-6, atol=1e-6)
+    for r in rep._replicas[1:]:
+        assert torch.equal(r[0].weight, w) and torch.equal(r[1].running_mean, rm)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        rep(x)
