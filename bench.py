@@ -454,6 +454,54 @@ def pmc_traffic(bf16, size, clips, dom_kernel):
         f"FETCH_SIZE x2 + WRITE_SIZE, KiB units; not measured live)")
 
 
+FWD_GFLOP_PER_FRAME = {18: 3.6286, 34: 7.3407, 50: 8.1743}     # 2 * MACs of the convolutions, 224 x 224 (a third of fwd + bwd)
+
+
+def measure_inference(size, frames, precision, steps, warmup, ctx):
+    """What every downstream user of R3M calls (/root/reference/r3m/__init__.py:72-75, r3m/example.py:19-33): `load_r3m(...).eval()`
+    forward under no_grad — `frames` frames of 224 x 224 per call and per GPU, running-statistics BatchNorm, no backward, no optimizer.
+    Same timing discipline as the training step (barrier + synchronize on both sides of exactly `steps` calls, max over ranks)."""
+    from r3m_amd import R3M
+    rank, world, dev, use_dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["use_dist"]
+    torch.manual_seed(1)
+    model = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0, precision=precision).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    x = torch.randint(0, 256, (frames, 3, 224, 224), generator=g, device=dev, dtype=torch.int32).float()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            h = model(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h = model(x)
+        barrier()
+        dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(h).all())
+    del model
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    ms = dt / steps * 1e3
+    tflops = FWD_GFLOP_PER_FRAME[size] * frames / ms                     # GFLOP / ms = TFLOP/s, per GPU
+    peak = 2500.0 if precision == "bf16" else 157.3
+    return {"metric": f"encoder frames/sec (forward only, eval) ResNet-{size} 224^2, {frames} frames/GPU", "value": round(frames * world / (dt / steps), 1),
+            "unit": "frames/s", "ms_per_call": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": "bf16" if precision == "bf16" else "f32",
+            "n_gpus": world, "workload": f"load_r3m-style eval forward under no_grad: ResNet-{size}, {frames} frames of 224x224x3 per GPU, "
+                                         f"{'bf16 activations' if precision == 'bf16' else 'fp32'}, running-statistics BatchNorm",
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                         "work": f"{FWD_GFLOP_PER_FRAME[size]} GFLOP per frame (forward convolutions) x {frames} frames per call, whole call"}}
+
+
 SECONDARY = [   # the other single-node BASELINE configs, timed AFTER the headline so that it is unperturbed
     ("configs[2]", dict(size=50, clips=256, precision="bf16", langweight=1.0, doaug="none")),
     ("configs[3]", dict(size=50, clips=256, precision="fp32", langweight=1.0, doaug="none")),
@@ -532,6 +580,16 @@ def main():
                         "workload": r["config"]["workload"], "collectives": r["config"]["collectives"],
                         "comm_exposed_ms": r.get("comm_exposed_ms"),
                         "roofline": {k: v for k, v in r["roofline"].items() if k != "kernels"}}
+                sec[name] = r
+        # inference: the call every downstream user makes, fp32 and bf16
+        for name, prec in (("inference_fp32", "fp32"), ("inference_bf16", "bf16")):
+            try:
+                r = measure_inference(50, 1280, prec, args.secondary_steps, args.secondary_warmup, ctx)
+            except Exception as e:
+                if use_dist:
+                    raise
+                r = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
                 sec[name] = r
         if rank == 0:
             out["secondary"] = sec
