@@ -42,6 +42,9 @@ int r3m_debug_set_pw16(int mode);
    csrc/conv_row16.hip; 0 = the per-tile halo kernels of csrc/conv_bf16.hip (rounds 3-5). The two accumulate the taps in different orders:
    stored elements agree to 1 bf16 ulp, not bit for bit. Returns the old value. */
 int r3m_debug_set_conv3x3_bf16(int mode);
+/* Diagnostic (same-process A/B, tests): 1 (default) = forwards with training = 2 run the fused inference sequence; 0 = they run the
+   training = 0 kernel sequence (conv, then a stand-alone BatchNorm + ReLU pass). Returns the old value. */
+int r3m_debug_set_fused_inference(int on);
 /* Diagnostic, runs without a GPU: which kernel family the gather-GEMM dispatch (csrc/conv.hip gg_route) picks for every launch of one
    convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual
    join, 64 BatchNorm-backward partials, mask_bits = 1: their ReLU mask comes as bits) — nothing is launched. routes[i]: 1 = 3x3 window
@@ -76,7 +79,12 @@ int r3m_resnet_tensor_info(r3m_resnet_t h, int i, char* name, int name_cap, int*
 /* backward stage s (0: avgpool+layer4, 1: layer3, 2: layer2, 3: layer1+stem) finishes params [offset, offset+count) */
 int r3m_resnet_stage_range(r3m_resnet_t h, int stage, long long* offset, long long* count);
 /* x: [frames,3,224,224] fp32 NCHW in 0..255 (models_r3m.py:96: "Input must be [0, 255]"); h_out: [frames, out_dim].
- * training=1: batch statistics + running-stat update (momentum 0.1, eps 1e-5); 0: running statistics. */
+ * training=1: batch statistics + running-stat update (momentum 0.1, eps 1e-5); 0: running statistics, everything a backward needs
+ * kept (fine-tuning with frozen statistics); 2: INFERENCE — running statistics and nothing kept: BatchNorm, the residual join and the
+ * ReLU are applied where each convolution stores its result (no raw conv outputs, no stand-alone BatchNorm passes, no mask bits), an
+ * identity block's sum overwrites its input. What `load_r3m(...).eval()` under torch.no_grad() runs (/root/reference/r3m/__init__.py:
+ * 72-75, r3m/example.py:19-33). fp32: bit-identical to training=0; bf16: one rounding per stored tensor instead of two (closer to
+ * float64). r3m_resnet_backward after it returns an error. */
 int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, float* buffers, void* arena, float* h_out,
                        int training, r3m_stream_t stream);
 /* dh: [frames, out_dim]. Runs stages [stage_begin, stage_end) in order. The stages of one backward share state inside the plan

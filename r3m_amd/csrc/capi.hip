@@ -192,6 +192,7 @@ int r3m_debug_occupy(int blocks, int lds_bytes, double milliseconds, r3m_stream_
 int r3m_debug_set_dynamic_tiles(int on) { return r3m::gg_set_dynamic_tiles(on); }
 int r3m_debug_set_pw16(int mode) { return r3m::pw16_set_mode(mode); }
 int r3m_debug_set_conv3x3_bf16(int mode) { return r3m::row16_set_mode(mode); }
+int r3m_debug_set_fused_inference(int on) { return r3m::engine_set_fused_inference(on); }
 int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
                          int* routes, int cap) {
   R3M_REQUIRE(routes && cap >= 1, "debug_conv_route: routes buffer");
@@ -272,12 +273,14 @@ int r3m_resnet_stage_range(r3m_resnet_t h, int stage, long long* offset, long lo
 int r3m_resnet_forward(r3m_resnet_t h, const float* x, const float* params, float* buffers, void* arena, float* h_out, int training,
                        r3m_stream_t stream) {
   R3M_REQUIRE(h && x && params && buffers && arena && h_out, "resnet_forward: null argument");
+  R3M_REQUIRE(training >= 0 && training <= 2, "resnet_forward: training=%d (0 eval, 1 train, 2 inference)", training);
   return plan_forward(*PLAN(h), x, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
 }
 int r3m_resnet_forward_crop(r3m_resnet_t h, const void* frames, int frames_are_u8, const int* boxes, int frames_per_box, int Hi, int Wi,
                             const float* params, float* buffers, void* arena, float* h_out, int training, r3m_stream_t stream) {
   R3M_REQUIRE(h && frames && boxes && params && buffers && arena && h_out, "resnet_forward_crop: null argument");
   R3M_REQUIRE(frames_per_box >= 1 && Hi >= 1 && Wi >= 1, "resnet_forward_crop: frames_per_box=%d, frames %dx%d", frames_per_box, Hi, Wi);
+  R3M_REQUIRE(training >= 0 && training <= 2, "resnet_forward_crop: training=%d (0 eval, 1 train, 2 inference)", training);
   const FrameSource src{frames, frames_are_u8, boxes, frames_per_box, Hi, Wi};
   return plan_forward_src(*PLAN(h), nullptr, &src, params, buffers, static_cast<float*>(arena), h_out, training, S(stream));
 }

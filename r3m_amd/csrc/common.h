@@ -55,6 +55,9 @@ enum : int {
                         // bn_y — also emit that BatchNorm's backward partials per 64 result rows: sum(g), sum(g * (y - mean)),
                         // g = dz * [relu mask] (mask: bn_bits, or recomputed as fma(y, bn_scale, bn_shift) > 0). Replaces the
                         // stand-alone first pass of BatchNorm backward (one read of dz and of y saved per layer).
+  EPI_AFFINE     = 128, // forward only (round 6, the inference path): out = acc * bn_scale[col] + bn_shift[col] — eval-mode BatchNorm
+                        // (running statistics) applied where the convolution result is stored; then EPI_ACCUM (+ the residual already
+                        // in `out`) and EPI_RELU in that order: relu(bn(conv(x)) + identity) of a block tail in ONE store.
 };
 
 // rows of the EPI_BNRED partial buffer one launch writes ([rows][2][Nc] floats): one per 64 GEMM rows, tile-independent
@@ -128,6 +131,7 @@ struct BnRedArgs {
   float* partial;
   int rows_out;              // partial rows written (all launches of the dgrad)
 };
+int engine_set_fused_inference(int on);
 int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
                          int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, BnRedArgs* br,
                          hipStream_t s);
@@ -135,6 +139,7 @@ int conv_dgrad_launch_br(const float* dY, const float* Wt, float* dX, const floa
 // ---- launchers (conv.hip) ----
 int launch_gather_gemm(const GatherGemmParams& p, hipStream_t s);
 double gather_gemm_alg_bytes(const GatherGemmParams& p, int elem_bytes);
+bool gather_gemm_fuses_affine(const GatherGemmParams& p);   // inference forward: the launch's kernel has the EPI_AFFINE epilogues
 int gather_gemm_grid_m(int M, int Nc);   // number of row blocks the launcher will use (stats partial rows)
 // The engine hands the NEXT launch_gather_gemm of this thread 8 zeroed device counters (dynamic tile queues of the persistent
 // kernel: a block that finds its CU shared with another stream's kernel — RCCL during an overlapped all-reduce — simply takes

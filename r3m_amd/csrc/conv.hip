@@ -961,6 +961,18 @@ static int gg_route(const GatherGemmParams& p) {
   if (R3M_ENV_INT("R3M_GG_PW", 1) && pw_gemm_eligible(p)) return GG_ROUTE_PW + pw_gemm_form(p);
   return glds2 ? GG_ROUTE_GLDS2 : GG_ROUTE_OTHER;
 }
+// inference forward: can this launch apply eval-mode BatchNorm (+ residual) (+ ReLU) where it stores (EPI_AFFINE family)? True for the
+// kernels every ResNet layer runs (the persistent kernel, the 3x3 window kernel; every bf16 kernel); the engine falls back to
+// conv + bn_act_fwd for anything else (odd shapes of the fuzz tests).
+bool gather_gemm_fuses_affine(const GatherGemmParams& p_in) {
+  GatherGemmParams p = p_in;
+  for (int t = 0; t < p.ntaps; ++t)
+    p.tap[t] = (int)((unsigned)(unsigned char)p.dy[t] | ((unsigned)(unsigned char)p.dx[t] << 8) | ((unsigned)p.wt[t] << 16));
+  if (p.dtype == DT_BF16) return (p.Nc & 7) == 0 && (p.Ci & 63) == 0;
+  const int r = gg_route(p);
+  if (r == GG_ROUTE_WIN) return p.flags == (EPI_AFFINE | EPI_RELU) || p.flags == (EPI_AFFINE | EPI_ACCUM | EPI_RELU);
+  return r > GG_ROUTE_PW && r < GG_ROUTE_K16;
+}
 static thread_local int* t_route_out = nullptr;      // dry run (r3m_debug_conv_route): record the route of every launch, launch nothing
 static thread_local int t_route_n = 0, t_route_cap = 0;
 void gg_route_record_begin(int* out, int cap) { t_route_out = out; t_route_n = 0; t_route_cap = cap; }
@@ -1020,7 +1032,12 @@ int launch_gather_gemm(const GatherGemmParams& p_in, hipStream_t s) {
     if (int e = ensure_dyn_lds(oi, reinterpret_cast<const void*>(conv3x3_win_kernel<128, 128, 2, 2, 192, E>), Cfg::LDS, "conv3x3_win")) return e; \
     hipLaunchKernelGGL((conv3x3_win_kernel<128, 128, 2, 2, 192, E>), dim3(grid), dim3(256), Cfg::LDS, s, p);                 \
   } while (0)
-        GG_EPI_SWITCH(LAUNCH_WIN)
+        switch (p.flags) {                       // inference forward (round 6): eval-mode BatchNorm (+ residual in `out`) + ReLU at the store
+          case EPI_AFFINE | EPI_RELU: LAUNCH_WIN(EPI_AFFINE | EPI_RELU); break;
+          case EPI_AFFINE | EPI_ACCUM | EPI_RELU: LAUNCH_WIN(EPI_AFFINE | EPI_ACCUM | EPI_RELU); break;
+          default:
+            GG_EPI_SWITCH(LAUNCH_WIN)
+        }
 #undef LAUNCH_WIN
         prof_bytes(gather_gemm_alg_bytes(p, 4));
         prof_end(s);

@@ -448,6 +448,8 @@ static int halo_launch(const GatherGemmParams& p, hipStream_t s) {
     case EPI_MASKED_ADD: return halo_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD>(p, s);
     case EPI_BNRED: return halo_launch_one<BM, BN, WM, WN, EPI_BNRED>(p, s);
     case EPI_BNRED | EPI_MASKED_ADD: return halo_launch_one<BM, BN, WM, WN, EPI_BNRED | EPI_MASKED_ADD>(p, s);
+    case EPI_AFFINE | EPI_RELU: return halo_launch_one<BM, BN, WM, WN, EPI_AFFINE | EPI_RELU>(p, s);
+    case EPI_AFFINE | EPI_ACCUM | EPI_RELU: return halo_launch_one<BM, BN, WM, WN, EPI_AFFINE | EPI_ACCUM | EPI_RELU>(p, s);
     default: set_last_error("conv3x3_halo(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }
@@ -465,7 +467,7 @@ static bool halo_eligible(const GatherGemmParams& p) {
   if (p.Hg != p.Hi || p.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || (p.Ci & 63) || (p.Nc & 7)) return false;
   if (!(p.Nc % 128 == 0 || p.Nc == 64)) return false;
   if (p.flags != 0 && p.flags != EPI_STATS && p.flags != EPI_ACCUM && p.flags != EPI_MASKED_ADD && p.flags != EPI_BNRED &&
-      p.flags != (EPI_BNRED | EPI_MASKED_ADD))
+      p.flags != (EPI_BNRED | EPI_MASKED_ADD) && p.flags != (EPI_AFFINE | EPI_RELU) && p.flags != (EPI_AFFINE | EPI_ACCUM | EPI_RELU))
     return false;
   for (int k = 0; k < 9; ++k)
     if (p.dy[k] < -1 || p.dy[k] > 1 || p.dx[k] < -1 || p.dx[k] > 1) return false;
@@ -510,6 +512,9 @@ static int gg16_launch(const GatherGemmParams& p, int grid, hipStream_t s) {
     case EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_MASKED_ADD, NST, BK>(p, grid, s);
     case EPI_BNRED: return gg16_launch_one<BM, BN, WM, WN, EPI_BNRED, NST, BK>(p, grid, s);
     case EPI_BNRED | EPI_MASKED_ADD: return gg16_launch_one<BM, BN, WM, WN, EPI_BNRED | EPI_MASKED_ADD, NST, BK>(p, grid, s);
+    case EPI_AFFINE: return gg16_launch_one<BM, BN, WM, WN, EPI_AFFINE, NST, BK>(p, grid, s);                           // inference forward (round 6)
+    case EPI_AFFINE | EPI_RELU: return gg16_launch_one<BM, BN, WM, WN, EPI_AFFINE | EPI_RELU, NST, BK>(p, grid, s);
+    case EPI_AFFINE | EPI_ACCUM | EPI_RELU: return gg16_launch_one<BM, BN, WM, WN, EPI_AFFINE | EPI_ACCUM | EPI_RELU, NST, BK>(p, grid, s);
     default: set_last_error("gather_gemm(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }

@@ -237,6 +237,8 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
   const int gcol = n0 + wn * CW + ecol;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if ((EPI & EPI_BIAS) && gcol < p.Nc) bias4 = ldg4(p.bias + gcol);
+  f32x4 aff_sc = {1.f, 1.f, 1.f, 1.f}, aff_sh = {0.f, 0.f, 0.f, 0.f};
+  if ((EPI & EPI_AFFINE) && gcol < p.Nc) { aff_sc = ldg4(p.bn_scale + gcol); aff_sh = ldg4(p.bn_shift + gcol); }
   BnRedAcc<4> bnacc;
   BnRedCoef<4> bncoef;
   if constexpr ((EPI & EPI_BNRED) != 0) {
@@ -290,6 +292,10 @@ __device__ __forceinline__ void gg_epilogue(const GatherGemmParams& p, f32x16 (&
         const long long roff = roff_of(row);
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol);
         OT* dst = reinterpret_cast<OT*>(p.out) + roff + gcol;     // activation pointers are typed float in the params struct;
+        if (EPI & EPI_AFFINE) {                                   // eval-mode BatchNorm: the same fmaf(y, scale, shift) bn_act_fwd computes
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], aff_sc[e], aff_sh[e]);
+        }
         if (EPI & EPI_BIAS) v += bias4;                           // with OT = bf16_t they address bf16 tensors
         if (EPI & EPI_ACCUM) v += opre[it % YPRE];
         if (EPI & EPI_MASKED_ADD) {
@@ -383,6 +389,24 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
     const int gx = rem - gy * p.Wg;
     return (((long long)n * p.Ho + (gy * p.os + p.ooy)) * p.Wo + (gx * p.os + p.oox)) * p.Nc;
   };
+  // EPI_AFFINE (inference forward): per-column coefficients — in the accumulator layout a lane owns column tn * 32 + lrow of the wave's
+  // columns (plain stores), in the store layout 8 consecutive columns from gcol (read-modify-write stores)
+  float aff_sc[TN], aff_sh[TN];
+  float aff_sc8[8], aff_sh8[8];
+  if constexpr ((EPI & EPI_AFFINE) != 0) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int c = min(n0 + wn * CW + tn * 32 + lrow, p.Nc - 1);
+      aff_sc[tn] = p.bn_scale[c];
+      aff_sh[tn] = p.bn_shift[c];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(gcol + e, p.Nc - 1);
+      aff_sc8[e] = RMW ? p.bn_scale[c] : 1.f;
+      aff_sh8[e] = RMW ? p.bn_shift[c] : 0.f;
+    }
+  }
   if constexpr (!RMW) {
     constexpr int CSH = CW + 8;          // slab row stride in bf16 (16-byte aligned rows, 4-bank skew)
     constexpr int TMP = TM > 2 ? 2 : TM; // row tiles per pass (64 slab rows per wave at most)
@@ -397,8 +421,12 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)acc[ps * TMP + tm][tn][r];
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[ps * TMP + tm][tn][r];
+            if constexpr ((EPI & EPI_AFFINE) != 0) v = fmaf(v, aff_sc[tn], aff_sh[tn]);     // eval-mode BatchNorm on the fp32 accumulator, one rounding
+            if constexpr ((EPI & EPI_RELU) != 0) v = fmaxf(v, 0.f);
+            slab[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CSH + tn * 32 + lrow] = (bf16_t)v;
+          }
       __builtin_amdgcn_wave_barrier();
       bool stored = false;
       {
@@ -498,10 +526,18 @@ __device__ __forceinline__ void gg_store_bf16(const GatherGemmParams& p, f32x16 
           const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + lr * CS + ecol + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+          if constexpr ((EPI & EPI_AFFINE) != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], aff_sc8[e], aff_sh8[e]);
+          }
           if (EPI & EPI_ACCUM) {
             const bf16x8 o = opre[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)o[e];
+          }
+          if constexpr ((EPI & EPI_RELU) != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           if (EPI & EPI_MASKED_ADD) {
             const bf16x8 g = gpre[it];

@@ -101,7 +101,8 @@ __device__ __forceinline__ const float* pw_uniform_ptr(const float* q) {   // a 
   return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
 }
 
-// EPI: 0, EPI_STATS, EPI_ACCUM, EPI_MASKED_ADD (1-bit mask only), EPI_BNRED, EPI_BNRED | EPI_MASKED_ADD
+// EPI: 0, EPI_STATS, EPI_ACCUM, EPI_MASKED_ADD (1-bit mask only), EPI_BNRED, EPI_BNRED | EPI_MASKED_ADD; inference forward (round 6):
+//      EPI_AFFINE, EPI_AFFINE | EPI_RELU, EPI_AFFINE | EPI_ACCUM | EPI_RELU (eval-mode BatchNorm, residual already in `out`, ReLU at the store)
 // YBITS (EPI_BNRED): the consumer BatchNorm's ReLU mask comes as bits (block outputs) / is recomputed from y (inner BatchNorms)
 // Two shapes: <128, 128, 2, 2> — four waves of 64 x 64, two blocks per CU — for outputs whose width is a multiple of 128, and
 // <256, 64, 4, 2> — EIGHT waves of 64 x 32 (TN = 1), one block per CU — for the 64-channel outputs (conv1 / the dgrad of conv3 in
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
   // ---- epilogue operands of the tile being computed, prefetched into registers (read-modify-write epilogues only)
   // acc[tm][tn][r] is row m0 + wm 64 + tm 32 + 8 (r >> 2) + 4 lh + (r & 3), column n0 + wn 64 + tn 32 + lrow.
   constexpr bool MADD = (EPI & EPI_MASKED_ADD) != 0, BNR = (EPI & EPI_BNRED) != 0, ACC = (EPI & EPI_ACCUM) != 0;
+  constexpr bool AFF = (EPI & EPI_AFFINE) != 0, RELU = (EPI & EPI_RELU) != 0;   // round 6, inference: eval-mode BatchNorm (+ residual in `out`) (+ ReLU) at the store
+  static_assert(!(AFF && (BNR || MADD)) && (!RELU || AFF), "EPI_AFFINE / EPI_RELU: forward epilogues");
   constexpr bool PRE = MADD || BNR || ACC;
   static_assert(!(MADD && ACC), "one added tensor");
   // Store layout (after the per-wave LDS transposition of the epilogue): a lane owns FOUR consecutive columns of one row; a
@@ -462,6 +465,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
         sh = *reinterpret_cast<const f32x4*>(p.bn_shift + col);
       }
     }
+    if constexpr (AFF) {
+      const int col = n0 + wn * CW + scol;
+      sc = *reinterpret_cast<const f32x4*>(p.bn_scale + col);
+      sh = *reinterpret_cast<const f32x4*>(p.bn_shift + col);
+    }
     static_for<8>([&](auto c_c) __attribute__((always_inline)) {
       constexpr int c = decltype(c_c)::value;             // chunk (tm, q): wave-tile rows 8 c .. 8 c + 7
       constexpr int tm = c >> 2, q = c & 3;
@@ -476,7 +484,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void pw_gemm_ke
       for (int i = 0; i < TN; ++i) {                      // TN stores of RPS rows each cover the chunk's 8 rows
         const int st = c * TN + i;                        // store index 0 .. NST - 1: rows st RPS + srow
         f32x4 v = *reinterpret_cast<const f32x4*>(slab_r + i * RPS * CW);
+        if constexpr (AFF) {                               // the same fmaf(y, scale, shift) bn_act_fwd computes (csrc/bn.hip)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        }
         if constexpr (ACC) v += pg[st];
+        if constexpr (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if constexpr (MADD) {
           const unsigned nb = mask_nibble(pgm, st);
 #pragma unroll
@@ -711,6 +727,8 @@ static int pw_cu_count() {
 static bool pw_flags_ok(const GatherGemmParams& p) {
   switch (p.flags) {
     case 0: case EPI_STATS: case EPI_ACCUM: case EPI_BNRED: return true;
+    case EPI_AFFINE: case EPI_AFFINE | EPI_RELU: case EPI_AFFINE | EPI_ACCUM | EPI_RELU:      // inference forward (dense output rows only)
+      return p.os == 1 && p.ooy == 0 && p.oox == 0 && p.Hg == p.Ho && p.Wg == p.Wo && p.bn_scale && p.bn_shift;
     case EPI_MASKED_ADD: case EPI_BNRED | EPI_MASKED_ADD: return p.addbits != nullptr;
     default: return false;
   }
@@ -749,7 +767,8 @@ bool pw_gemm_eligible(const GatherGemmParams& p) { return pw_gemm_form(p) != 0; 
 // blocks per CU) the two issue orders measured the same within noise. Built for the three epilogues those launches use.
 static bool pw_burst(const GatherGemmParams& p) {
   const long long ktot = (long long)(p.simple_rows ? 1 : p.ntaps) * p.Ci;
-  return (p.Nc & 127) != 0 && ktot >= 2LL * p.Nc && (p.flags == EPI_STATS || p.flags == 0 || (p.flags == EPI_BNRED && !p.bn_bits));
+  return (p.Nc & 127) != 0 && ktot >= 2LL * p.Nc &&
+         (p.flags == EPI_STATS || p.flags == 0 || p.flags == (EPI_AFFINE | EPI_RELU) || (p.flags == EPI_BNRED && !p.bn_bits));
 }
 
 static bool pw_tile512() { return R3M_ENV_INT("R3M_PW_512", 1) != 0; }   // probe builds: 0 = the 256 x 64 tile everywhere (A/B)
@@ -794,6 +813,7 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
     switch (p.flags) {
       case 0: LAUNCH_PW_BURST(0); return 0;
       case EPI_STATS: LAUNCH_PW_BURST(EPI_STATS); return 0;
+      case EPI_AFFINE | EPI_RELU: LAUNCH_PW_BURST(EPI_AFFINE | EPI_RELU); return 0;
       case EPI_BNRED: LAUNCH_PW_BURST(EPI_BNRED); return 0;
     }
   }
@@ -805,6 +825,9 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
     case 0: LAUNCH_PW(0, false); break;
     case EPI_STATS: LAUNCH_PW(EPI_STATS, false); break;
     case EPI_ACCUM: LAUNCH_PW(EPI_ACCUM, false); break;
+    case EPI_AFFINE: LAUNCH_PW(EPI_AFFINE, false); break;
+    case EPI_AFFINE | EPI_RELU: LAUNCH_PW(EPI_AFFINE | EPI_RELU, false); break;
+    case EPI_AFFINE | EPI_ACCUM | EPI_RELU: LAUNCH_PW(EPI_AFFINE | EPI_ACCUM | EPI_RELU, false); break;
     case EPI_MASKED_ADD: LAUNCH_PW(EPI_MASKED_ADD, false); break;
     case EPI_BNRED:
       if (!yb) LAUNCH_PW(EPI_BNRED, false);

@@ -401,6 +401,8 @@ int row16_launch(const GatherGemmParams& p, hipStream_t s) {
     case EPI_MASKED_ADD: return row16_launch_one<BN, EPI_MASKED_ADD>(p, s);
     case EPI_BNRED: return row16_launch_one<BN, EPI_BNRED>(p, s);
     case EPI_BNRED | EPI_MASKED_ADD: return row16_launch_one<BN, EPI_BNRED | EPI_MASKED_ADD>(p, s);
+    case EPI_AFFINE | EPI_RELU: return row16_launch_one<BN, EPI_AFFINE | EPI_RELU>(p, s);                               // inference forward
+    case EPI_AFFINE | EPI_ACCUM | EPI_RELU: return row16_launch_one<BN, EPI_AFFINE | EPI_ACCUM | EPI_RELU>(p, s);
     default: set_last_error("conv3x3_row(bf16): unsupported epilogue flag combination %d", p.flags); return 1;
   }
 }
@@ -422,7 +424,7 @@ bool row16_eligible(const GatherGemmParams& p) {
   if (!((p.Nc & 127) == 0 || p.Nc == 64)) return false;
   if (ceil_div((R_BM + 2 * p.Wi + 2) * 5, 64) * 1024 > ((p.Nc & 127) == 0 ? RowCfg<128>::ZOFF : RowCfg<64>::ZOFF)) return false;
   if (p.flags != 0 && p.flags != EPI_STATS && p.flags != EPI_ACCUM && p.flags != EPI_MASKED_ADD && p.flags != EPI_BNRED &&
-      p.flags != (EPI_BNRED | EPI_MASKED_ADD))
+      p.flags != (EPI_BNRED | EPI_MASKED_ADD) && p.flags != (EPI_AFFINE | EPI_RELU) && p.flags != (EPI_AFFINE | EPI_ACCUM | EPI_RELU))
     return false;
   if ((long long)p.Nc * p.T * p.Ci * 2 >= (long long)BUF_OOB) return false;
   for (int k = 0; k < 9; ++k)

@@ -298,6 +298,36 @@ int conv_forward_launch(const float* X, const float* W, float* Y, float* stats, 
   return launch_gather_gemm(g, s);
 }
 
+// Inference forward (round 6): the convolution stores [relu]( acc * scale[co] + shift[co] [+ what `out` already holds] ) — eval-mode
+// BatchNorm, the residual join and the ReLU in the conv's own store (flags: EPI_AFFINE [| EPI_ACCUM] [| EPI_RELU]).
+static void fill_forward_params(GatherGemmParams& g, const float* X, const float* W, float* out, const float* scale, const float* shift,
+                                int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt) {
+  memset(&g, 0, sizeof g);
+  g.dtype = dt;
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  g.A = X; g.B = W; g.out = out; g.bn_scale = scale; g.bn_shift = shift;
+  g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
+  g.Hg = Ho; g.Wg = Wo; g.Ho = Ho; g.Wo = Wo; g.Nc = Co;
+  g.is = stride; g.os = 1; g.ooy = 0; g.oox = 0;
+  g.M = N * Ho * Wo;
+  g.T = k * k;
+  fill_taps_fwd(g, k, pad);
+  g.flags = flags;
+  g.simple_rows = (k == 1 && stride == 1 && pad == 0) ? 1 : 0;
+}
+bool conv_forward_affine_fusable(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt) {
+  GatherGemmParams g;
+  static const float one = 1.f;   // (the query looks at shapes, flags and whether the coefficient pointers are set — never dereferenced)
+  fill_forward_params(g, nullptr, nullptr, nullptr, &one, &one, N, Hi, Wi, Ci, Co, k, stride, pad, flags, dt);
+  return gather_gemm_fuses_affine(g);
+}
+int conv_forward_launch_affine(const float* X, const float* W, float* out, const float* scale, const float* shift, int N, int Hi, int Wi,
+                               int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s) {
+  GatherGemmParams g;
+  fill_forward_params(g, X, W, out, scale, shift, N, Hi, Wi, Ci, Co, k, stride, pad, flags, dt);
+  return launch_gather_gemm(g, s);
+}
+
 // dX[N,Hi,Wi,Ci] = dgrad of conv(k, stride, pad) given dY[N,Ho,Wo,Co] and Wt[Ci][k*k][Co]
 int conv_dgrad_launch(const float* dY, const float* Wt, float* dX, const float* add0, const float* add1, const unsigned* addbits,
                       int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, int flags, int dt, hipStream_t s) {
@@ -391,6 +421,9 @@ size_t conv_wgrad_ws_floats(int N, int Hi, int Wi, int Ci, int Co, int k, int st
   return (size_t)split * Co * k * k * Ci;
 }
 
+static int g_fused_inference = 1;   // r3m_debug_set_fused_inference: 0 = inference forwards run the unfused eval sequence (A/B, tests)
+int engine_set_fused_inference(int on) { const int old = g_fused_inference; g_fused_inference = on ? 1 : 0; return old; }
+
 #define TRY(x)              \
   do {                      \
     if (int e_ = (x)) return e_; \
@@ -448,9 +481,13 @@ int plan_forward(Plan& P, const float* x_nchw, const float* params, float* bufs,
 // stem pre-pass)
 int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, const float* params, float* bufs, float* arena,
                      float* h_out, int training, hipStream_t s) {
+  // training: 1 = batch statistics (+ running-statistics update), 0 = running statistics with everything a backward needs kept,
+  // 2 = INFERENCE (round 6): running statistics, nothing kept — BatchNorm, residual join and ReLU ride in the convolutions' stores
+  const bool infer = training == 2;
+  if (infer) training = 0;
   Ctx c{P, params, nullptr, bufs, arena, s, training, 0, P.dtype};
   P.last_training = training;
-  P.next_stage = 0;            // a new forward invalidates whatever an unfinished backward left behind
+  P.next_stage = infer ? -3 : 0;   // a new forward invalidates whatever an unfinished backward left behind (-3: nothing to differentiate)
   P.dout_fused_rows = 0;
   const int F = P.F;
   const int dt = P.dtype;
@@ -491,6 +528,82 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
   TRY(launch_bn_relu_maxpool_fwd(arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), arena + P.P0_off,
                                  reinterpret_cast<unsigned char*>(arena + P.amax_off), F, 112, 112, 64, dt, s));
   // ---- residual stages ----
+  if (infer && g_fused_inference) {
+    // Inference: per block, every convolution stores its activated output itself — inner convs relu(bn(conv)), the downsample conv
+    // bn(conv), the last conv relu(bn(conv) + residual) accumulating ONTO the residual (the block input, in place, or the downsample
+    // result): no raw conv output, no bn_act_fwd pass, no mask bits. A block any of whose launches runs a kernel without these
+    // epilogues (odd shapes; never a ResNet layer) takes the unfused sequence below instead.
+    const float* cur_in = arena + P.blocks[0].in_off;
+    for (const BlockSpec& B : P.blocks) {
+      const int nlast = B.conv[B.nconv - 1];
+      bool fus = true;
+      for (int j = 0; j < B.nconv; ++j) {
+        const ConvSpec& L = P.convs[B.conv[j]];
+        const int fl = j < B.nconv - 1 ? (EPI_AFFINE | EPI_RELU) : (EPI_AFFINE | EPI_ACCUM | EPI_RELU);
+        fus = fus && conv_forward_affine_fusable(F, L.Hi, L.Wi, L.Ci, L.Co, L.k, L.stride, L.pad, fl, dt);
+      }
+      if (B.ds >= 0) {
+        const ConvSpec& Ld = P.convs[B.ds];
+        fus = fus && conv_forward_affine_fusable(F, Ld.Hi, Ld.Wi, Ld.Ci, Ld.Co, Ld.k, Ld.stride, Ld.pad, EPI_AFFINE, dt);
+      }
+      auto coeffs = [&](const ConvSpec& L) {
+        return launch_bn_eval_coeffs(params + L.gamma_off, params + L.beta_off, bufs + L.rm_off, bufs + L.rv_off, 1e-5f, coef(c, L, 0),
+                                     coef(c, L, 1), coef(c, L, 2), coef(c, L, 3), L.Co, s);
+      };
+      auto fused = [&](const ConvSpec& L, const float* X, float* out, int flags) {
+        gg_set_tile_counters(reinterpret_cast<unsigned*>(arena + P.ctr_off) + (&L - P.convs.data()) * 8);
+        struct DropCounters { ~DropCounters() { gg_set_tile_counters(nullptr, 0); } } drop;
+        return conv_forward_launch_affine(X, fwd_weights(c, L), out, coef(c, L, 2), coef(c, L, 3), F, L.Hi, L.Wi, L.Ci, L.Co, L.k,
+                                          L.stride, L.pad, flags, dt, s);
+      };
+      if (fus) {
+        const float* cur = cur_in;
+        for (int j = 0; j < B.nconv - 1; ++j) {
+          const ConvSpec& L = P.convs[B.conv[j]];
+          TRY(coeffs(L));
+          TRY(fused(L, cur, arena + L.Z_off, EPI_AFFINE | EPI_RELU));
+          cur = arena + L.Z_off;
+        }
+        float* res = const_cast<float*>(cur_in);       // identity block: the sum replaces the block input
+        if (B.ds >= 0) {
+          const ConvSpec& Ld = P.convs[B.ds];
+          TRY(coeffs(Ld));
+          res = arena + Ld.Y_off;
+          TRY(fused(Ld, cur_in, res, EPI_AFFINE));
+        }
+        const ConvSpec& LL = P.convs[nlast];
+        TRY(coeffs(LL));
+        TRY(fused(LL, cur, res, EPI_AFFINE | EPI_ACCUM | EPI_RELU));
+        cur_in = res;
+      } else {
+        const float* cur = cur_in;
+        for (int j = 0; j < B.nconv; ++j) {
+          const ConvSpec& L = P.convs[B.conv[j]];
+          TRY(conv_bn(c, L, cur));
+          if (j < B.nconv - 1) {
+            TRY(launch_bn_act_fwd(arena + L.Y_off, coef(c, L, 2), coef(c, L, 3), nullptr, nullptr, nullptr, arena + L.Z_off,
+                                  (long long)F * L.Ho * L.Wo, L.Co, 1, nullptr, dt, s));
+            cur = arena + L.Z_off;
+          }
+        }
+        const ConvSpec& LL = P.convs[nlast];
+        const long long rows = (long long)F * B.Ho * B.Wo;
+        if (B.ds >= 0) {
+          const ConvSpec& Ld = P.convs[B.ds];
+          TRY(conv_bn(c, Ld, cur_in));
+          TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), arena + Ld.Y_off, coef(c, Ld, 2), coef(c, Ld, 3),
+                                arena + B.out_off, rows, B.Co, 1, nullptr, dt, s));
+        } else {
+          TRY(launch_bn_act_fwd(arena + LL.Y_off, coef(c, LL, 2), coef(c, LL, 3), cur_in, nullptr, nullptr, arena + B.out_off, rows,
+                                B.Co, 1, nullptr, dt, s));
+        }
+        cur_in = arena + B.out_off;
+      }
+    }
+    const BlockSpec& lastb = P.blocks.back();
+    TRY(launch_avgpool_fwd(cur_in, h_out, F, lastb.Ho * lastb.Wo, lastb.Co, dt, s));
+    return 0;
+  }
   for (const BlockSpec& B : P.blocks) {
     const float* Xin = arena + B.in_off;
     const float* cur = Xin;
@@ -651,6 +764,7 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
   Ctx c{P, params, grads, nullptr, arena, s, P.last_training, accumulate, P.dtype};
   const int dt = P.dtype;
   R3M_REQUIRE(stage_begin >= 0 && stage_end <= 4 && stage_begin < stage_end, "resnet_backward: stages [%d, %d) outside [0, 4)", stage_begin, stage_end);
+  R3M_REQUIRE(P.next_stage != -3, "resnet_backward: the last forward on this plan ran in inference mode (training = 2): nothing was kept for a backward");
   R3M_REQUIRE(P.next_stage != -1, "resnet_backward: no forward has run on this plan");
   // stage 0 may always (re)start a backward over the saved activations (retain_graph); any other stage must continue the
   // sequence the previous call left off at — its inputs (running output gradient, pending EPI_BNRED partials) live in the plan

@@ -379,16 +379,19 @@ class HipResNet(nn.Module):
             slot.arena = torch.empty(need, dtype=torch.uint8, device=src.device)
         arena = slot.arena
         out = torch.empty((F, self.outdim), dtype=torch.float32, device=src.device)
+        # 1 train / 0 eval with the activations kept for a backward / 2 inference: eval statistics and nothing kept — BatchNorm, residual
+        # join and ReLU ride in the convolutions' stores (what load_r3m(...).eval() under no_grad runs, /root/reference/r3m/__init__.py:72-75)
+        mode = 1 if training else (0 if saved else 2)
         with _lib.on(src):
             if crop is not None:
                 _lib.check(L.r3m_resnet_forward_crop(h, crop.raw.data_ptr(), 1 if crop.raw.dtype == torch.uint8 else 0,
                                                      crop.boxes.data_ptr(), crop.frames_per_box, crop.raw.shape[-2], crop.raw.shape[-1],
                                                      self._flat_p.data_ptr(), self._flat_b.data_ptr(), arena.data_ptr(),
-                                                     out.data_ptr(), 1 if training else 0, _lib.stream_ptr(src.device)),
+                                                     out.data_ptr(), mode, _lib.stream_ptr(src.device)),
                            "resnet_forward_crop")
             else:
                 _lib.check(L.r3m_resnet_forward(h, x.data_ptr(), self._flat_p.data_ptr(), self._flat_b.data_ptr(),
-                                                arena.data_ptr(), out.data_ptr(), 1 if training else 0,
+                                                arena.data_ptr(), out.data_ptr(), mode,
                                                 _lib.stream_ptr(x.device)), "resnet_forward")
         if training:
             self._flat_nbt += 1

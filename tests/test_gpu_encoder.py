@@ -581,3 +581,67 @@ def test_encoder_gradients_kink_free_case(hip, golden_dir, size):
         if d["worst"][0] > max(4.0 * d["worst"][1], 1e-4):
             fails.append(("worst", i, d["worst"]))
     assert not fails, fails
+
+
+# ---- round 6: the inference path (r3m_resnet_forward with training = 2) ------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("size", [18, 34, 50])
+def test_inference_forward_fused_vs_unfused(hip, size, precision):
+    """`load_r3m(...).eval()` under torch.no_grad() (/root/reference/r3m/__init__.py:72-75, r3m/example.py:19-33) runs the inference
+    sequence: eval-mode BatchNorm, the residual join and the ReLU are applied where each convolution stores its result
+    (EPI_AFFINE | EPI_ACCUM | EPI_RELU), no stand-alone BatchNorm pass runs. Against the unfused eval sequence (conv, then bn_act_fwd;
+    r3m_debug_set_fused_inference(0)) on the same weights and frames:
+      fp32: BIT-IDENTICAL embeddings (the fused store computes the same fmaf(y, scale, shift) [+ residual] and max(., 0) on the same
+            fp32 values), for a frame count that fills whole tiles and for a ragged one;
+      bf16: the fused store rounds ONCE (the conv result is never stored) where the unfused pair rounds twice — embeddings agree to
+            1e-2 l2-rel and the fused one is at least as close to the float64 emulation-free truth of the same bf16-rounded weights.
+    A grad-enabled eval forward keeps the saved-state sequence (training = 0): its backward still works and matches."""
+    from r3m_amd import R3M
+    torch.manual_seed(5)
+    m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0, precision=precision)
+    _load_state(m.convnet)
+    m = m.to(DEV).eval()
+    for F in (8, 5):
+        x = torch.randint(0, 256, (F, 3, 224, 224), device=DEV).float()
+        with torch.no_grad():
+            old = hip.r3m_debug_set_fused_inference(1)
+            try:
+                h_f = m(x)
+                hip.r3m_debug_set_fused_inference(0)
+                h_u = m(x)
+            finally:
+                hip.r3m_debug_set_fused_inference(old)
+        assert torch.isfinite(h_f).all()
+        if precision == "fp32":
+            assert torch.equal(h_f, h_u), float((h_f - h_u).abs().max())
+        else:
+            d = float((h_f - h_u).norm() / h_u.norm())
+            report(f"r{size} bf16 inference, {F} frames: fused vs unfused eval embedding l2-rel {d:.3e}")
+            assert d < 1e-2
+    # the saved-state eval forward (grad enabled) is unchanged and differentiable; an inference forward is not
+    x = torch.randint(0, 256, (4, 3, 224, 224), device=DEV).float()
+    h = m(x)
+    with torch.no_grad():
+        h_inf = m(x)
+    if precision == "fp32":
+        assert torch.equal(h.detach(), h_inf)
+    h.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.convnet.parameters())
+
+
+def test_inference_forward_keeps_nothing_for_a_backward(hip):
+    """C ABI contract: r3m_resnet_backward after a training = 2 forward is an error (the activations were overwritten in place)."""
+    from r3m_amd import R3M
+    m = R3M("cuda", 1e-4, 1024, size=18, langweight=0.0, tcnweight=1.0).to(DEV).eval()
+    x = torch.randint(0, 256, (2, 3, 224, 224), device=DEV).float()
+    with torch.no_grad():
+        m(x)
+    conv = m.convnet
+    si, _ = conv._last_forward
+    slot = conv._slot(si)
+    plan = slot.plans[2]
+    dh = torch.ones((2, conv.outdim), device=DEV)
+    g = conv.flat_grads()
+    rc = hip.r3m_resnet_backward(plan, dh.data_ptr(), conv.flat_params().data_ptr(), g.data_ptr(), slot.arena.data_ptr(), 0, 4, 0,
+                                 torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"inference mode" in hip.r3m_last_error()
