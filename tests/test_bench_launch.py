@@ -64,10 +64,12 @@ def test_headline_detection_and_secondary_set():
                   ["--encoder-only-frames", "256"], ["--clips-per-gpu", "8"]):
         assert not bench.is_headline(_args(*flags)), flags
     names = [n for n, _ in bench.SECONDARY]
-    assert names == ["configs[2]", "configs[3]", "configs[4]"]
-    lab = {n: bench.workload_label(dict(w, encoder_only_frames=0), 1) for n, w in bench.SECONDARY}
-    for n in names:                                        # each secondary workload is labelled as the config it is
+    assert names == ["configs[2]", "configs[3]", "configs[4]", "encoder_only_256_frames"]
+    lab = {n: bench.workload_label(dict({"encoder_only_frames": 0}, **w), 1) for n, w in bench.SECONDARY}
+    for n in names[:3]:                                    # each secondary BASELINE workload is labelled as the config it is
         assert lab[n].startswith("BASELINE " + n), (n, lab[n])
+    assert lab["encoder_only_256_frames"] == "encoder-only continuity point"      # (the literal "bs=256/GPU" reading)
+    assert set(bench.FWD_GFLOP_PER_FRAME) == {18, 34, 50} and abs(3 * bench.FWD_GFLOP_PER_FRAME[50] - 24.2868) < 0.3
     assert bench.workload_label(dict(size=50, precision="fp32", langweight=0.0, doaug="none", encoder_only_frames=0), 8).startswith(
         "BASELINE configs[1], replicated on 8 GPUs")
 
