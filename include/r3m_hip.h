@@ -45,10 +45,6 @@ int r3m_debug_set_conv3x3_bf16(int mode);
 /* Diagnostic (same-process A/B, tests): 1 (default) = forwards with training = 2 run the fused inference sequence; 0 = they run the
    training = 0 kernel sequence (conv, then a stand-alone BatchNorm + ReLU pass). Returns the old value. */
 int r3m_debug_set_fused_inference(int on);
-/* Diagnostic (same-process A/B, tests): 1 (default) = every BatchNorm combine (partial rows -> fp64 slices -> coefficients, forward
-   and backward) is ONE launch whose last-arriving block finalizes; 0 = the two-launch form (slice reduce, then finalize). Same bits
-   either way. Returns the old value. */
-int r3m_debug_set_bn_combine(int on);
 /* Diagnostic, runs without a GPU: which kernel family the gather-GEMM dispatch (csrc/conv.hip gg_route) picks for every launch of one
    convolution forward (dgrad = 0; flags: 1 = BatchNorm statistics) or input gradient (dgrad = 1; flags: 2 accumulate, 4 masked residual
    join, 64 BatchNorm-backward partials, mask_bits = 1: their ReLU mask comes as bits) — nothing is launched. routes[i]: 1 = 3x3 window

@@ -28,7 +28,6 @@ SIGNATURES = {
     "r3m_debug_set_pw16": (c_i, [c_i]),
     "r3m_debug_set_conv3x3_bf16": (c_i, [c_i]),
     "r3m_debug_set_fused_inference": (c_i, [c_i]),
-    "r3m_debug_set_bn_combine": (c_i, [c_i]),
     "r3m_debug_conv_route": (c_i, [c_i] * 12 + [C.POINTER(c_i), c_i]),
     "r3m_profile_enable": (None, [c_i]),
     "r3m_profile_classes": (C.c_uint, [C.c_uint]),

@@ -10,7 +10,6 @@
 #include "common.h"
 #include "conv_dev.h"
 #include <cstdlib>
-#include <cstring>
 
 // Traversal order of the streaming BatchNorm passes. The 256 MiB Infinity Cache still holds the TAIL of the tensor the previous
 // kernel streamed; a consumer that walks the rows in the opposite direction hits it first. R3M_BN_REV bit 1: forward apply, bit 2:
@@ -116,9 +115,8 @@ size_t bn_acc_bytes(int C) {
   int cap = 131072 / (C > 0 ? C : 1);
   if (cap > 256) cap = 256;
   if (cap < 64) cap = 64;
-  return (size_t)cap * 2 * C * 8 + 256;   // + the 64 ticket words of the one-launch combine (bn_combine_kernel), at the tail
+  return (size_t)cap * 2 * C * 8;
 }
-unsigned* bn_acc_tickets(double* acc, int C) { return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(acc) + bn_acc_bytes(C) - 256); }
 
 // acc must hold 131072 * 2 doubles (64 slices x 2 x 2048 channels, or more slices of fewer channels); the slice count is a pure function of the partial-row count (reduce_slices), so
 // the finalize launchers below take the same `stat_rows` and recompute it.
@@ -158,13 +156,15 @@ __device__ __forceinline__ bool slice_totals(const double* __restrict__ acc, int
   return g == 0 && c < C;
 }
 
-// channel c's totals (sum y, sum y^2 in fp64) -> mean / invstd / scale / shift (+ the running-statistics update): shared by the
-// stand-alone finalize kernel and the one-launch combine below, so both produce the same bits
-__device__ __forceinline__ void bn_coeffs_of_totals(int c, double s, double ss, double inv_count, double unbias,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                                    float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                                    float* __restrict__ scale_o, float* __restrict__ shift_o) {
+__global__ __launch_bounds__(64 * SG) void bn_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
+                                                           double unbias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum, float eps,
+                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                           float* __restrict__ scale_o, float* __restrict__ shift_o, int C) {
+  int c;
+  double s, ss;
+  if (!slice_totals(acc, S, C, &c, &s, &ss)) return;
   const double mean = s * inv_count;
   double var = ss * inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -180,18 +180,6 @@ __device__ __forceinline__ void bn_coeffs_of_totals(int c, double s, double ss, 
     running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * meanf;
     running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * unbias);
   }
-}
-
-__global__ __launch_bounds__(64 * SG) void bn_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
-                                                           double unbias, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float momentum, float eps,
-                                                           float* __restrict__ mean_o, float* __restrict__ invstd_o,
-                                                           float* __restrict__ scale_o, float* __restrict__ shift_o, int C) {
-  int c;
-  double s, ss;
-  if (!slice_totals(acc, S, C, &c, &s, &ss)) return;
-  bn_coeffs_of_totals(c, s, ss, inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean_o, invstd_o, scale_o, shift_o);
 }
 
 // `stat_rows` = number of partial rows that were reduced (fixes the slice count), `count` = elements per channel.
@@ -548,17 +536,6 @@ int launch_bn_bwd_reduce(const void* dZ, const void* Zmask, const unsigned* Zbit
   return check_launch("bn_bwd_reduce");
 }
 
-__device__ __forceinline__ void bn_bwd_of_totals(int c, double sg, double sgy, double inv_count, int use_batch_stats,
-                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c1,
-                                                 float* __restrict__ c2, int accumulate, const float* __restrict__ second_sum_scale) {
-  if (second_sum_scale) sgy *= (double)second_sum_scale[c];    // EPI_BNRED partials carry sum(g (y - mean)): x invstd = sum(g yhat)
-  const float db = (float)sg, dg = (float)sgy;
-  dbeta[c] = accumulate ? dbeta[c] + db : db;
-  dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-  c1[c] = use_batch_stats ? (float)(sg * inv_count) : 0.f;
-  c2[c] = use_batch_stats ? (float)(sgy * inv_count) : 0.f;
-}
-
 __global__ __launch_bounds__(64 * SG) void bn_bwd_finalize_kernel(const double* __restrict__ acc, int S, double inv_count,
                                                                int use_batch_stats, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ c1,
@@ -567,7 +544,12 @@ __global__ __launch_bounds__(64 * SG) void bn_bwd_finalize_kernel(const double* 
   int c;
   double sg, sgy;
   if (!slice_totals(acc, S, C, &c, &sg, &sgy)) return;
-  bn_bwd_of_totals(c, sg, sgy, inv_count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, second_sum_scale);
+  if (second_sum_scale) sgy *= (double)second_sum_scale[c];    // EPI_BNRED partials carry sum(g (y - mean)): x invstd = sum(g yhat)
+  const float db = (float)sg, dg = (float)sgy;
+  dbeta[c] = accumulate ? dbeta[c] + db : db;
+  dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  c1[c] = use_batch_stats ? (float)(sg * inv_count) : 0.f;
+  c2[c] = use_batch_stats ? (float)(sgy * inv_count) : 0.f;
 }
 
 int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long count, int use_batch_stats, float* dgamma,
@@ -576,140 +558,6 @@ int launch_bn_bwd_finalize_rows(const double* acc, int stat_rows, long long coun
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * SG), 0, s, acc, reduce_slices(stat_rows, C),
                      1.0 / (double)count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C, second_sum_scale);
   return check_launch("bn_bwd_finalize");
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// One launch per BatchNorm combine (round 6): partial rows -> fp64 slices -> coefficients.
-// Phase 1 is bn_stats_reduce_kernel's block (same rows per thread, same order). The block that arrives LAST at its column
-// block's ticket then does what the finalize kernels did: the 16 slice groups of slice_totals, four per thread, combined in group
-// order — the same additions in the same order, so the coefficients carry the same bits as the two-launch form
-// (tests/test_gpu_encoder.py::test_bn_combine_one_launch_is_bit_identical). The ticket re-arms itself (the last block stores 0 after
-// every slice block has arrived), the caller zeroes it once.
-// ---------------------------------------------------------------------------------------------------------
-struct BnCombineArgs {
-  double inv_count, unbias;            // unbias: forward only
-  const float *gamma, *beta;           // forward
-  float *running_mean, *running_var;   // forward (null: no update)
-  float momentum, eps;
-  float *o0, *o1, *o2, *o3;            // forward: mean, invstd, scale, shift; backward: dgamma, dbeta, c1, c2
-  const float* second_sum_scale;       // backward
-  int use_batch_stats, accumulate;     // backward
-};
-template <bool BWD>
-__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ partials, int rows, int C, double* __restrict__ acc,
-                                                          unsigned* __restrict__ tickets, BnCombineArgs a) {
-  __shared__ double red[2][SG][64];
-  __shared__ unsigned is_last;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
-  const int S = gridDim.y;
-  double s = 0.0, ss = 0.0;
-  if (c < C) {
-    for (int r = blockIdx.y * 4 + ty; r < rows; r += 4 * S) {
-      s += (double)partials[((long long)r * 2 + 0) * C + c];
-      ss += (double)partials[((long long)r * 2 + 1) * C + c];
-    }
-  }
-  red[0][ty][tx] = s;
-  red[1][ty][tx] = ss;
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    s = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-    ss = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
-    __hip_atomic_store(&acc[((long long)blockIdx.y * 2 + 0) * C + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&acc[((long long)blockIdx.y * 2 + 1) * C + c], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // No agent-scope FENCE anywhere: a release / acquire fence at agent scope writes back / invalidates the XCD's whole L2
-  // (buffer_wbl2 / buffer_inv sc1) — every block of every combine doing that cost +75 us per launch (profiles/r06_bn_combine_ab.txt,
-  // first build). The slices travel as agent-scope relaxed ATOMIC stores and loads instead (sc1: written through to / read from the
-  // level all XCDs share), ordered by hand: the stores are acknowledged (vmcnt 0) before the barrier in front of the ticket, and the
-  // last block's loads issue after its ticket came back.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = t == (unsigned)(S - 1);
-    if (is_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // slice_totals with 4 waves: thread (tx, ty) walks groups ty, ty + 4, ty + 8, ty + 12 (group g = slices g, g + SG, ...); the
-  // loads of four slices of each of its four groups are in flight together (they bypass the L2: ~1 us each)
-  double gs[4] = {0.0, 0.0, 0.0, 0.0}, gss[4] = {0.0, 0.0, 0.0, 0.0};
-  if (c < C) {
-    for (int i = ty; i < S; i += 4 * SG) {
-      double v[4][4], vv[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int sl = i + SG * u + 4 * q;
-          v[u][q] = vv[u][q] = 0.0;
-          if (sl < S) {
-            v[u][q] = __hip_atomic_load(&acc[((long long)sl * 2 + 0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            vv[u][q] = __hip_atomic_load(&acc[((long long)sl * 2 + 1) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i + SG * u + 4 * q < S) { gs[q] += v[u][q]; gss[q] += vv[u][q]; }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    red[0][ty + 4 * q][tx] = gs[q];
-    red[1][ty + 4 * q][tx] = gss[q];
-  }
-  __syncthreads();
-  if (ty != 0 || c >= C) return;
-  s = red[0][0][tx];
-  ss = red[1][0][tx];
-#pragma unroll
-  for (int k = 1; k < SG; ++k) { s += red[0][k][tx]; ss += red[1][k][tx]; }
-  if (BWD) bn_bwd_of_totals(c, s, ss, a.inv_count, a.use_batch_stats, a.o0, a.o1, a.o2, a.o3, a.accumulate, a.second_sum_scale);
-  else bn_coeffs_of_totals(c, s, ss, a.inv_count, a.unbias, a.gamma, a.beta, a.running_mean, a.running_var, a.momentum, a.eps, a.o0, a.o1, a.o2, a.o3);
-}
-
-static int g_bn_combine = 1;   // r3m_debug_set_bn_combine: 0 = the two-launch form (slice reduce, then finalize) for A/Bs and the bit-identity test
-int bn_set_combine(int on) { const int old = g_bn_combine; g_bn_combine = on ? 1 : 0; return old; }
-
-int launch_bn_stats_coeffs(const float* partials, int stat_rows, int C, double* acc, unsigned* tickets, long long count,
-                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                           float* mean, float* invstd, float* scale, float* shift, hipStream_t s) {
-  if (!g_bn_combine || !tickets) {
-    if (int e = launch_bn_stats_reduce(partials, stat_rows, C, acc, s)) return e;
-    return launch_bn_finalize_rows(acc, stat_rows, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, s);
-  }
-  R3M_REQUIRE(C <= 64 * 64, "bn_stats_coeffs: C=%d needs more than 64 tickets", C);
-
-  BnCombineArgs a = {};
-  a.inv_count = 1.0 / (double)count;
-  a.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
-  a.momentum = momentum; a.eps = eps;
-  a.o0 = mean; a.o1 = invstd; a.o2 = scale; a.o3 = shift;
-  hipLaunchKernelGGL((bn_combine_kernel<false>), dim3(ceil_div(C, 64), reduce_slices(stat_rows, C)), dim3(256), 0, s, partials, stat_rows,
-                     C, acc, tickets, a);
-  return check_launch("bn_combine");
-}
-
-int launch_bn_stats_bwd(const float* partials, int stat_rows, int C, double* acc, unsigned* tickets, long long count, int use_batch_stats,
-                        float* dgamma, float* dbeta, float* c1, float* c2, int accumulate, hipStream_t s, const float* second_sum_scale) {
-  if (!g_bn_combine || !tickets) {
-    if (int e = launch_bn_stats_reduce(partials, stat_rows, C, acc, s)) return e;
-    return launch_bn_bwd_finalize_rows(acc, stat_rows, count, use_batch_stats, dgamma, dbeta, c1, c2, accumulate, C, s, second_sum_scale);
-  }
-  R3M_REQUIRE(C <= 64 * 64, "bn_stats_bwd: C=%d needs more than 64 tickets", C);
-
-  BnCombineArgs a = {};
-  a.inv_count = 1.0 / (double)count;
-  a.use_batch_stats = use_batch_stats; a.accumulate = accumulate; a.second_sum_scale = second_sum_scale;
-  a.o0 = dgamma; a.o1 = dbeta; a.o2 = c1; a.o3 = c2;
-  hipLaunchKernelGGL((bn_combine_kernel<true>), dim3(ceil_div(C, 64), reduce_slices(stat_rows, C)), dim3(256), 0, s, partials, stat_rows,
-                     C, acc, tickets, a);
-  return check_launch("bn_combine_bwd");
 }
 
 // pass 2:  dY = scale * (g - c1 - yhat * c2)       (c1 = mean(g), c2 = mean(g*yhat); both 0 in eval mode)

@@ -193,7 +193,6 @@ int r3m_debug_set_dynamic_tiles(int on) { return r3m::gg_set_dynamic_tiles(on); 
 int r3m_debug_set_pw16(int mode) { return r3m::pw16_set_mode(mode); }
 int r3m_debug_set_conv3x3_bf16(int mode) { return r3m::row16_set_mode(mode); }
 int r3m_debug_set_fused_inference(int on) { return r3m::engine_set_fused_inference(on); }
-int r3m_debug_set_bn_combine(int on) { return r3m::bn_set_combine(on); }
 int r3m_debug_conv_route(int N, int H, int W, int Ci, int Co, int k, int stride, int pad, int dgrad, int flags, int mask_bits, int dtype,
                          int* routes, int cap) {
   R3M_REQUIRE(routes && cap >= 1, "debug_conv_route: routes buffer");
@@ -426,12 +425,7 @@ int r3m_stem_conv_wgrad_bf16(const void* xn16, const void* dy, float* dw_ohwi, v
   return launch_stem_wgrad16(xn16, dy, dw_ohwi, static_cast<float*>(ws), frames, accumulate, S(stream));
 }
 
-// the caller's workspace holds arbitrary bytes: the 64 tickets of the one-launch combine are zeroed on the stream before every use
-static int zero_tickets(unsigned* tk, hipStream_t s) {
-  if (hipMemsetAsync(tk, 0, 256, s) != hipSuccess) { set_last_error("bn: cannot zero the combine tickets"); return 1; }
-  return 0;
-}
-// workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: slices*2*C doubles + 64 tickets]
+// workspace: [partials: bn_bwd_partial_rows*2*C floats][acc: 64*2*C doubles]
 static size_t bn_acc_off(long long rows, int C) {
   size_t p = (size_t)bn_bwd_partial_rows(rows, C, DT_F32) * 2 * C * 4;   // the fp32 geometry has the most rows
   return (p + 255) / 256 * 256;
@@ -443,10 +437,9 @@ int r3m_bn_train_coeffs(const float* stats, int stats_rows, long long count, con
                         float* rv, float momentum, float eps, float* coef, void* ws, size_t ws_bytes, int C, r3m_stream_t stream) {
   R3M_REQUIRE(ws_bytes >= bn_acc_bytes(C), "bn_train_coeffs: workspace too small (need %zu)", bn_acc_bytes(C));
   double* acc = static_cast<double*>(ws);
-  unsigned* tk = bn_acc_tickets(acc, C);
-  if (zero_tickets(tk, S(stream))) return 1;
-  return launch_bn_stats_coeffs(stats, stats_rows, C, acc, tk, count, gamma, beta, rm, rv, momentum, eps, coef, coef + C, coef + 2 * C,
-                                coef + 3 * C, S(stream));
+  if (int e = launch_bn_stats_reduce(stats, stats_rows, C, acc, S(stream))) return e;
+  return launch_bn_finalize_rows(acc, stats_rows, count, gamma, beta, rm, rv, momentum, eps, coef, coef + C, coef + 2 * C,
+                                 coef + 3 * C, C, S(stream));
 }
 int r3m_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* coef, int C,
                        r3m_stream_t stream) {
@@ -474,9 +467,8 @@ int r3m_bn_bwd_dt(const void* dz, const void* zmask, const unsigned* zbits, cons
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
   if (int e = launch_bn_bwd_reduce(dz, zmask, zbits, y, scale, shift, mean, invstd, partial, rows, C, dtype, S(stream))) return e;
   const int prow = bn_bwd_partial_rows(rows, C, dtype);
-  unsigned* tk = bn_acc_tickets(acc, C);
-  if (zero_tickets(tk, S(stream))) return 1;
-  if (int e = launch_bn_stats_bwd(partial, prow, C, acc, tk, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, S(stream))) return e;
+  if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
+  if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
   return launch_bn_bwd_apply(dz, zmask, zbits, y, scale, shift, mean, invstd, c12, c12 + C, dy, rows, C, dtype, S(stream));
 }
 int r3m_bn_bwd(const float* dz, const float* zmask, const unsigned* zbits, const float* y, const float* coef, float* dgamma,
@@ -503,9 +495,8 @@ int r3m_bn_maxpool_bwd_dt(const void* dp, const unsigned char* am, const void* y
   const float *mean = coef, *invstd = coef + C, *scale = coef + 2 * C, *shift = coef + 3 * C;
   if (int e = launch_bn_bwd_reduce_pool(dp, am, y, scale, shift, mean, invstd, partial, N, Hi, Wi, C, dtype, S(stream))) return e;
   const int prow = bn_bwd_pool_partial_rows(N, Hi, Wi, C);
-  unsigned* tk = bn_acc_tickets(acc, C);
-  if (zero_tickets(tk, S(stream))) return 1;
-  if (int e = launch_bn_stats_bwd(partial, prow, C, acc, tk, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, S(stream))) return e;
+  if (int e = launch_bn_stats_reduce(partial, prow, C, acc, S(stream))) return e;
+  if (int e = launch_bn_bwd_finalize_rows(acc, prow, rows, use_batch_stats, dgamma, dbeta, c12, c12 + C, accumulate, C, S(stream))) return e;
   return launch_bn_bwd_apply_pool(dp, am, y, scale, shift, mean, invstd, c12, c12 + C, dy, N, Hi, Wi, C, dtype, S(stream));
 }
 int r3m_maxpool_fwd_dt(const void* z, void* p, unsigned char* am, int N, int Hi, int Wi, int C, int dtype, r3m_stream_t stream) {

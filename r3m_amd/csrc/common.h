@@ -198,17 +198,7 @@ int launch_stem_wgrad16(const void* xn16, const void* dY, float* dw147, float* w
 
 // ---- launchers (bn.hip) ----
 size_t bn_acc_bytes(int C);   // fp64 slice accumulator: [slices <= max(64, min(256, 131072 / C))][2][C]
-unsigned* bn_acc_tickets(double* acc, int C);   // the 64 ticket words at the tail of a bn_acc_bytes(C) accumulator
 int launch_bn_stats_reduce(const float* partials, int rows, int C, double* acc /* bn_acc_bytes(C) */, hipStream_t s);
-// partial rows -> coefficients in ONE launch (bn_combine_kernel: slice reduce, the last block of each column block finalizes);
-// tickets: 64 zeroed words (they re-arm themselves); null, or bn_set_combine(0): the two-launch form. Same bits either way.
-int bn_set_combine(int on);
-int launch_bn_stats_coeffs(const float* partials, int stat_rows, int C, double* acc, unsigned* tickets, long long count,
-                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                           float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
-int launch_bn_stats_bwd(const float* partials, int stat_rows, int C, double* acc, unsigned* tickets, long long count, int use_batch_stats,
-                        float* dgamma, float* dbeta, float* c1, float* c2, int accumulate, hipStream_t s,
-                        const float* second_sum_scale = nullptr);
 int launch_bn_finalize_rows(const double* acc, int stat_rows, long long count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
                             float* invstd, float* scale, float* shift, int C, hipStream_t s);

@@ -67,7 +67,6 @@ struct Plan {
   long long stage_param_begin[5];  // params of stem+layer1 | layer2 | layer3 | layer4 boundaries (see stage_range)
   // arena offsets (floats)
   long long col_off, P0_off, amax_off, partial_off, acc_off, wt_off, wgp_off;
-  long long tk_off = 0;     // 64 unsigned: column-block tickets of bn_combine_kernel (self re-arming; zeroed with the forward tile queues)
   long long ctr_off = 0;    // [convs][8] + [convs][4][8] unsigned: per-XCD tile queues of the persistent kernel — the forward launch of each conv, and the (up to four: stride-2 parity classes) backward launches
   long long G_off[5];     // gradient ping-pong buffers: D (block output grad), A0/A1 (dY, alternating), B, C
   long long E_off = -1;   // dY of a downsample block's downsample BatchNorm: written with the block's last BatchNorm backward (one pass
@@ -245,7 +244,6 @@ Plan* plan_create(int size, int F, int dtype) {
   }
   if (dtype == DT_BF16) P.w16_off = take((P.n_params + 1) / 2);
   P.wgp_off = take(wgp_max);
-  P.tk_off = take(64);   // tickets of the one-launch BatchNorm combines, directly before the tile queues: one memset zeroes both
   P.ctr_off = take(5LL * (long long)P.convs.size() * 8);
   P.gmax = gmax;
   for (int g = 0; g < 5; ++g) P.G_off[g] = take(gmax);
@@ -432,7 +430,6 @@ int engine_set_fused_inference(int on) { const int old = g_fused_inference; g_fu
   } while (0)
 
 static float* coef(Ctx& c, const ConvSpec& L, int which) { return c.arena + L.coef_off + (long long)which * L.Co; }
-static unsigned* tickets(Ctx& c) { return reinterpret_cast<unsigned*>(c.arena + c.P.tk_off); }
 
 // conv -> (training: batch statistics -> coefficients | eval: running statistics -> coefficients)
 static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float* W, int Ci_eff, int k_eff, int stride_eff,
@@ -453,8 +450,9 @@ static int conv_bn_coeffs(Ctx& c, const ConvSpec& L, const float* X, const float
   const float* beta = c.params + L.beta_off;
   if (c.training) {
     const long long count = (long long)P.F * L.Ho * L.Wo;
-    TRY(launch_bn_stats_coeffs(partial, L.stats_rows, L.Co, acc, tickets(c), count, gamma, beta, c.bufs + L.rm_off, c.bufs + L.rv_off, 0.1f,
-                               1e-5f, coef(c, L, 0), coef(c, L, 1), coef(c, L, 2), coef(c, L, 3), c.s));
+    TRY(launch_bn_stats_reduce(partial, L.stats_rows, L.Co, acc, c.s));
+    TRY(launch_bn_finalize_rows(acc, L.stats_rows, count, gamma, beta, c.bufs + L.rm_off, c.bufs + L.rv_off, 0.1f, 1e-5f,
+                                coef(c, L, 0), coef(c, L, 1), coef(c, L, 2), coef(c, L, 3), L.Co, c.s));
   } else {
     TRY(launch_bn_eval_coeffs(gamma, beta, c.bufs + L.rm_off, c.bufs + L.rv_off, 1e-5f, coef(c, L, 0), coef(c, L, 1),
                               coef(c, L, 2), coef(c, L, 3), L.Co, c.s));
@@ -494,7 +492,7 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
   const int F = P.F;
   const int dt = P.dtype;
   // tile queues of this pass's persistent-kernel launches (conv_pw.hip): 8 counters per conv, zeroed here, each used by one launch
-  if (hipMemsetAsync(arena + P.tk_off, 0, (64 + P.convs.size() * 8) * sizeof(unsigned), s) != hipSuccess) {
+  if (hipMemsetAsync(arena + P.ctr_off, 0, P.convs.size() * 8 * sizeof(unsigned), s) != hipSuccess) {
     set_last_error("resnet_forward: cannot reset the tile queues");
     return 1;
   }
@@ -517,9 +515,10 @@ int plan_forward_src(Plan& P, const float* x_nchw, const FrameSource* crop, cons
     if (dt == DT_BF16) TRY(launch_stem_fwd16(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, s));
     else TRY(launch_stem_fwd(arena + P.col_off, params + L0.w_off, arena + L0.Y_off, training ? partial : nullptr, F, dt, s));
     if (training) {
-      TRY(launch_bn_stats_coeffs(partial, L0.stats_rows, 64, acc, tickets(c), (long long)F * 12544, params + L0.gamma_off,
-                                 params + L0.beta_off, bufs + L0.rm_off, bufs + L0.rv_off, 0.1f, 1e-5f, coef(c, L0, 0), coef(c, L0, 1),
-                                 coef(c, L0, 2), coef(c, L0, 3), s));
+      TRY(launch_bn_stats_reduce(partial, L0.stats_rows, 64, acc, s));
+      TRY(launch_bn_finalize_rows(acc, L0.stats_rows, (long long)F * 12544, params + L0.gamma_off, params + L0.beta_off,
+                                  bufs + L0.rm_off, bufs + L0.rv_off, 0.1f, 1e-5f, coef(c, L0, 0), coef(c, L0, 1), coef(c, L0, 2),
+                                  coef(c, L0, 3), 64, s));
     } else {
       TRY(launch_bn_eval_coeffs(params + L0.gamma_off, params + L0.beta_off, bufs + L0.rm_off, bufs + L0.rv_off, 1e-5f,
                                 coef(c, L0, 0), coef(c, L0, 1), coef(c, L0, 2), coef(c, L0, 3), 64, s));
@@ -651,8 +650,9 @@ static int bn_backward_sums(Ctx& c, const ConvSpec& L, const float* dZ, const un
     TRY(launch_bn_bwd_reduce(dZ, nullptr, Zbits, Y, coef(c, L, 2), coef(c, L, 3), coef(c, L, 0), coef(c, L, 1), partial, rows, L.Co, c.dt, c.s));
     prow = bn_bwd_partial_rows(rows, L.Co, c.dt);
   }
-  return launch_bn_stats_bwd(partial, prow, L.Co, acc, tickets(c), rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off,
-                             coef(c, L, 4), coef(c, L, 5), c.accumulate, c.s, fused_rows ? coef(c, L, 1) : nullptr);
+  TRY(launch_bn_stats_reduce(partial, prow, L.Co, acc, c.s));
+  return launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + L.gamma_off, c.grads + L.beta_off, coef(c, L, 4),
+                                     coef(c, L, 5), c.accumulate, L.Co, c.s, fused_rows ? coef(c, L, 1) : nullptr);
 }
 static int bn_backward(Ctx& c, const ConvSpec& L, const float* dZ, const unsigned* Zbits, float* dY, int fused_rows = 0) {
   TRY(bn_backward_sums(c, L, dZ, Zbits, fused_rows));
@@ -679,8 +679,9 @@ static int bn_backward_pair(Ctx& c, const ConvSpec& L, const ConvSpec& Ld, const
     const ConvSpec* two[2] = {&L, &Ld};
     for (int k = 0; k < 2; ++k) {
       const ConvSpec& Q = *two[k];
-      TRY(launch_bn_stats_bwd(partial + k * set, prow, Q.Co, acc, tickets(c), rows, P.last_training, c.grads + Q.gamma_off,
-                              c.grads + Q.beta_off, coef(c, Q, 4), coef(c, Q, 5), c.accumulate, c.s, nullptr));
+      TRY(launch_bn_stats_reduce(partial + k * set, prow, Q.Co, acc, c.s));
+      TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, c.grads + Q.gamma_off, c.grads + Q.beta_off, coef(c, Q, 4),
+                                      coef(c, Q, 5), c.accumulate, Q.Co, c.s, nullptr));
     }
   } else {
     TRY(bn_backward_sums(c, L, dZ, Zbits, fused_rows));
@@ -946,8 +947,9 @@ int plan_backward(Plan& P, const float* dh, const float* params, float* grads, f
         TRY(launch_bn_bwd_reduce_pool(Gp(0), am, arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), coef(c, L0, 0), coef(c, L0, 1), partial,
                                       F, 112, 112, 64, dt, s));
         const int prow = bn_bwd_pool_partial_rows(F, 112, 112, 64);
-        TRY(launch_bn_stats_bwd(partial, prow, 64, acc, tickets(c), rows, P.last_training, grads + L0.gamma_off, grads + L0.beta_off,
-                                coef(c, L0, 4), coef(c, L0, 5), accumulate, s));
+        TRY(launch_bn_stats_reduce(partial, prow, 64, acc, s));
+        TRY(launch_bn_bwd_finalize_rows(acc, prow, rows, P.last_training, grads + L0.gamma_off, grads + L0.beta_off, coef(c, L0, 4),
+                                        coef(c, L0, 5), accumulate, 64, s));
         TRY(launch_bn_bwd_apply_pool(Gp(0), am, arena + L0.Y_off, coef(c, L0, 2), coef(c, L0, 3), coef(c, L0, 0), coef(c, L0, 1),
                                      coef(c, L0, 4), coef(c, L0, 5), Gc, F, 112, 112, 64, dt, s));
       }

@@ -445,41 +445,6 @@ def test_paired_bn_backward_is_bit_identical(hip, size, F, precision):
         assert not bad, (training, bad[:5])
 
 
-@pytest.mark.parametrize("size,F,precision", [(18, 5, "fp32"), (34, 3, "bf16"), (50, 4, "fp32"), (50, 3, "bf16")])
-def test_bn_combine_one_launch_is_bit_identical(hip, size, F, precision):
-    """Round 6: every BatchNorm combine — partial rows -> fp64 slices -> coefficients, forward and backward — is ONE
-    launch whose last-arriving block finalizes (csrc/bn.hip bn_combine_kernel) instead of a slice-reduce launch + a finalize launch.
-    Same additions in the same order: embeddings, running statistics and every parameter gradient must be BIT-identical with the
-    switch on and off, train and eval, and again on a second step (the tickets re-arm themselves)."""
-    from oracle import detgen
-    from r3m_amd import R3M, _lib
-    L = _lib.lib()
-    x = torch.from_numpy(detgen.frames("frames8", (8, 3, 224, 224)))[:F].to(DEV)
-    res = {}
-    try:
-        for on in (1, 0):
-            assert L.r3m_debug_set_bn_combine(on) in (0, 1)
-            m = R3M("cuda", 1e-4, 1024, size=size, langweight=0.0, tcnweight=1.0, precision=precision)
-            _load_state(m.convnet)
-            m = m.to(DEV)
-            out = []
-            for training in (True, True, False):
-                m.train(training)
-                m.encoder_opt.zero_grad()
-                h = m(x)
-                cw = torch.from_numpy(detgen.uniform("cw", tuple(h.shape), 0.5, 1.5)).to(DEV)
-                (h * cw).sum().backward()
-                out.append((h.detach().clone(), {k: p.grad.detach().clone() for k, p in m.convnet.named_parameters()},
-                            {k: b.detach().clone() for k, b in m.convnet.state_dict().items() if "running" in k}))
-            res[on] = out
-    finally:
-        L.r3m_debug_set_bn_combine(1)
-    for (h1, g1, b1), (h0, g0, b0) in zip(res[1], res[0]):
-        assert torch.equal(h1, h0)
-        bad = [k for k in g0 if not torch.equal(g0[k], g1[k])] + [k for k in b0 if not torch.equal(b0[k], b1[k])]
-        assert not bad, bad[:5]
-
-
 def test_second_forward_before_backward(hip):
     """The reference encoder is a plain autograd graph (models_r3m.py:84-100): h1 = enc(x1); h2 = enc(x2); backward through both
     works. Here a forward's activations live in a preallocated arena: with the default of one arena the FIRST forward's backward

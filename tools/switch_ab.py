@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU: same-process A/B of one process-wide library switch (an `r3m_debug_set_*` entry point of include/r3m_hip.h) on whole training
 steps of a BASELINE config: same model, same arena, interleaved legs of `steps` steps each with the switch off / on.
-usage: switch_ab.py <switch> c1|c2|c4 [legs] [steps]      e.g.  switch_ab.py bn_combine c1 3 10
+usage: switch_ab.py <switch> c1|c2|c4 [legs] [steps]      e.g.  switch_ab.py conv3x3_bf16 c4 3 10
 (c1 = configs[1] ResNet-50 fp32 1280 frames; c2 = configs[2] ResNet-50 bf16 + language head; c4 = configs[4] ResNet-34 bf16 rctraj)"""
 import os
 import sys
