@@ -29,6 +29,7 @@ def csrc_sha16():
 def short_name(k):
     """kernel-trace names of kernels with bf16 arguments come back mangled (the tracer's demangler does not know DF16b): keep
     namespace-less function name + template arguments in their mangled form"""
+    k = k.replace("_ZN3r3m12_GLOBAL__N_1", "_ZN3r3m")          # kernels of an anonymous namespace inside r3m (conv_row16.hip)
     m = re.match(r"_ZN3r3m(\d+)", k)
     if not m:
         return k

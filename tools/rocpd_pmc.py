@@ -7,7 +7,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name or "")
+    name = re.sub(r"\(.*$", "", (name or "").replace("(anonymous namespace)::", ""))
     return name.replace("void ", "").replace("r3m::", "")[:100]
 
 
