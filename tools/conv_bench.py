@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of single conv launches through the C ABI (GPU only).
+env: CONV_BENCH_DATA=randn|zeros|ones (operand values), CONV_BENCH_REPS (timed launches, default 10)
 usage: conv_bench.py [fwd|wgrad|dgradbn|dgradbnres|fwd16|wgrad16|...] N,H,Ci,Co,k,s,p ...   (the *16 modes run the bf16 kernels)
 dgradbn: dgrad with the EPI_BNRED epilogue (mask recomputed from y); dgradbnres: + mask bits + masked residual-gradient join"""
 import os
@@ -20,6 +21,10 @@ for spec in sys.argv[2:]:
     Ho = (H + 2 * p - k) // s + 1
     x = torch.randn((N, H, H, Ci), device="cuda")
     w = torch.randn((Co, k, k, Ci), device="cuda") * 0.05
+    data = os.environ.get("CONV_BENCH_DATA", "randn")      # zeros / ones: the same instruction stream on operands that do not toggle the multipliers
+    if data != "randn":
+        x.fill_(0.0 if data == "zeros" else 1.0)
+        w.fill_(0.0 if data == "zeros" else 1.0)
     y = torch.empty((N, Ho, Ho, Co), device="cuda")
     if bf16:
         x, w, y = x.bfloat16(), w.bfloat16(), y.bfloat16()
@@ -31,7 +36,7 @@ for spec in sys.argv[2:]:
         stats = torch.empty((2 * rows + 2, 2, Co), device="cuda")   # (room for experiments with finer statistics rows)
         fn = lambda: L.r3m_conv2d_fwd_dt(x.data_ptr(), w.data_ptr(), y.data_ptr(), stats.data_ptr(), N, H, H, Ci, Co, k, s, p, dt, st)
     elif mode in ("dgradbn", "dgradbnres"):
-        dy = torch.randn_like(y)
+        dy = torch.randn_like(y) if data == "randn" else torch.full_like(y, 0.0 if data == "zeros" else 1.0)
         dx = torch.empty_like(x)
         by = torch.randn_like(x)
         res = torch.randn_like(x) if mode == "dgradbnres" else None
@@ -49,7 +54,7 @@ for spec in sys.argv[2:]:
                                                  P(res), P(rbits), by.data_ptr(), P(ybits), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
                                                  part.data_ptr(), dt, st)
     else:
-        dy = torch.randn_like(y)
+        dy = torch.randn_like(y) if data == "randn" else torch.full_like(y, 0.0 if data == "zeros" else 1.0)
         dw = torch.empty(w.shape, device="cuda")
         wsb = L.r3m_conv2d_wgrad_workspace_bytes_dt(N, H, H, Ci, Co, k, s, p, dt)
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
@@ -58,7 +63,7 @@ for spec in sys.argv[2:]:
         assert fn() == 0, L.r3m_last_error()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
+    reps = int(os.environ.get("CONV_BENCH_REPS", "10"))
     e0.record()
     for _ in range(reps):
         fn()
