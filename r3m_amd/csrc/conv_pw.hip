@@ -850,11 +850,8 @@ static int launch_pw_shape(const GatherGemmParams& p_in, hipStream_t s) {
 int launch_pw_gemm(const GatherGemmParams& p, hipStream_t s) {
   const bool wide = (p.Nc & 127) == 0;
   const int form = pw_gemm_form(p);
-#ifdef R3M_PROBES
-  // experiment (probe builds): 64-wide pointwise launches on a 128 x 64 tile, four waves, three blocks per CU — more bytes in flight
-  // per CU than the eight-wave tile's one block. Its statistics rows are per 128 result rows: the caller must size for that.
-  if (form == 1 && !wide && R3M_ENV_INT("R3M_PW_N128", 0)) return launch_pw_shape<128, 64, 2, 2, false>(p, s);
-#endif
+  // (round 4's probe-build experiment of a 128 x 64 tile at three blocks per CU — profiles/r04_narrow_tile128_ab.txt: no gain — left the
+  // file in round 6: its statistics rows no longer nest in the 256-row geometry the kernel asserts since the 512 x 64 tile)
   if (form == 3) return wide ? launch_pw_shape<128, 128, 2, 2, true, true>(p, s) : launch_pw_shape<256, 64, 4, 2, true, true>(p, s);
   // 64-channel outputs, contracting launches (the burst form: conv1 / conv2 forward, conv2 / conv3 dgrad of layer1): 512 x 64 tile, eight
   // waves of 64 x 64 like the 128-wide kernel's — half the fragment reads and barriers per MFMA of the 256 x 64 tile's 64 x 32 waves

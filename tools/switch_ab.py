@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU: same-process A/B of one process-wide library switch (an `r3m_debug_set_*` entry point of include/r3m_hip.h) on whole training
 steps of a BASELINE config: same model, same arena, interleaved legs of `steps` steps each with the switch off / on.
-usage: switch_ab.py <switch> c1|c2|c4 [legs] [steps]      e.g.  switch_ab.py conv3x3_bf16 c4 3 10
+usage: switch_ab.py <switch> c1|c2|c4 [legs] [steps] [on-value]      e.g.  switch_ab.py conv3x3_bf16 c4 3 10   (on-value: what "on" passes, default 1)
 (c1 = configs[1] ResNet-50 fp32 1280 frames; c2 = configs[2] ResNet-50 bf16 + language head; c4 = configs[4] ResNet-34 bf16 rctraj)"""
 import os
 import sys
@@ -15,6 +15,7 @@ from r3m_amd.trainer import Trainer
 switch, cfg = sys.argv[1], sys.argv[2]
 legs = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+on_value = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 L = _lib.lib()
 setter = getattr(L, "r3m_debug_set_" + switch)
 dev = "cuda:0"
@@ -44,7 +45,7 @@ res = {0: [], 1: []}
 default = setter(1)
 for leg in range(legs):
     for on in (0, 1):
-        setter(on)
+        setter(on_value if on else 0)
         for i in range(2):
             tr.update(net, (get(), langs), i)
         torch.cuda.synchronize()
