@@ -92,7 +92,17 @@ __device__ __forceinline__ float div_const(float x, float d, float rcp) {
 // elements, three 16-byte stores) so the horizontal sample position and weights are computed once per pixel instead of once
 // per element; p / 255 comes from a 256-entry table (p is a byte) and the two remaining divisions by constants use div_const.
 // Operation order per element is bilinear_sample + stem_normalize's (augment_dev.h); the GPU tests compare the two bit for bit.
+// Round 6: the source bytes arrive as unaligned DWORD loads shared by the two taps of a pixel and — whenever the four taps of a
+// pixel PAIR lie within four consecutive bytes (down-sampling factors up to 1.5: every box of 256-wide clips) — by both pixels:
+// 24-48 loads per thread instead of 96 byte loads. The kernel was bound by exactly those (each byte load of a wave touches the
+// same 5-9 cache lines its neighbours do: 1.0 ms for 2560 frames at 0.16 of the HBM roof). A load never leaves its source row:
+// its address is clamped to the row's last four bytes and the byte positions shift accordingly.
 constexpr int XN_GROUPS = (XN_ROW + 23) / 24;      // 30 groups of 24 elements; the last one holds 8 (padding) elements
+__device__ __forceinline__ unsigned ld_u32_unaligned(const unsigned char* p) {
+  unsigned w;
+  __builtin_memcpy(&w, p, 4);
+  return w;
+}
 __global__ __launch_bounds__(256) void stem_prep16_crop_u8_kernel(const unsigned char* __restrict__ raw, const int* __restrict__ boxes,
                                                                    bf16_t* __restrict__ xn16, long long total, int Hi, int Wi, int fpb) {
 #pragma clang fp contract(off)
@@ -122,28 +132,56 @@ __global__ __launch_bounds__(256) void stem_prep16_crop_u8_kernel(const unsigned
     const float ly = sy - (float)y0, hy = 1.f - ly;
     const float xscale = (float)bw / 224.0f;
     const long long plane = (long long)Hi * Wi;
-    const unsigned char* p0 = raw + f * 3 * plane + (long long)(top + y0) * Wi + left;
-    const unsigned char* p1 = raw + f * 3 * plane + (long long)(top + y1) * Wi + left;
+    const unsigned char* r0 = raw + f * 3 * plane + (long long)(top + y0) * Wi;      // source rows (column 0 of the clip, not of the box)
+    const unsigned char* r1 = raw + f * 3 * plane + (long long)(top + y1) * Wi;
+    const int amax = Wi - 4;                                  // last column a dword load may start at inside a row (launcher: Wi >= 4)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int ix = g * 8 - 3 + k;
-      if ((unsigned)ix >= 224u) continue;
-      const float sx = fmaxf(fmaf((float)ix + 0.5f, xscale, -0.5f), 0.f);
-      const int x0 = (int)sx;
-      const int x1 = x0 + (x0 < bw - 1 ? 1 : 0);
-      const float lx = sx - (float)x0, hx = 1.f - lx;
+    for (int kk = 0; kk < 4; ++kk) {
+      // the two pixels of the pair: sample columns, weights, validity
+      int x0[2], x1[2];
+      float lx[2], hx[2];
+      bool ok[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ix = g * 8 - 3 + 2 * kk + h;
+        ok[h] = (unsigned)ix < 224u;
+        const float sx = fmaxf(fmaf((float)(ok[h] ? ix : 0) + 0.5f, xscale, -0.5f), 0.f);
+        x0[h] = (int)sx;
+        x1[h] = x0[h] + (x0[h] < bw - 1 ? 1 : 0);
+        lx[h] = sx - (float)x0[h];
+        hx[h] = 1.f - lx[h];
+      }
+      if (!ok[0] && !ok[1]) continue;
+      // dword A starts at pixel 0's left tap (clamped into the row); pixel 1 shares it when its right tap still lies inside
+      const int ca = left + x0[0], cb = left + x0[1];
+      const int aa = min(ca, amax);
+      const bool share = (left + x1[1] - aa <= 3) && (cb >= aa);
+      const int ab = share ? aa : min(cb, amax);
+      const int s00 = 8 * (ca - aa), s01 = 8 * (left + x1[0] - aa);          // bit positions of pixel 0's taps in dword A
+      const int s10 = 8 * (cb - ab), s11 = 8 * (left + x1[1] - ab);          // of pixel 1's taps in dword B (= A when shared)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float v00 = lut[p0[c * plane + x0]], v01 = lut[p0[c * plane + x1]];
-        const float v10 = lut[p1[c * plane + x0]], v11 = lut[p1[c * plane + x1]];
-        const float t0 = fmaf(hx, v00, lx * v01);
-        const float t1 = fmaf(hx, v10, lx * v11);
-        const float v = fmaf(hy, t0, ly * t1) * 255.0f;
-        const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
-        const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
-        const float rsd = c == 0 ? 1.0f / 0.229f : (c == 1 ? 1.0f / 0.224f : 1.0f / 0.225f);
-        const float n = div_const(div_const(v, 255.0f, 1.0f / 255.0f) - mean, sd, rsd);
-        o[(k * 3 + c) >> 3][(k * 3 + c) & 7] = (bf16_t)n;
+        const unsigned wa0 = ld_u32_unaligned(r0 + c * plane + aa);
+        const unsigned wa1 = ld_u32_unaligned(r1 + c * plane + aa);
+        const unsigned wb0 = share ? wa0 : ld_u32_unaligned(r0 + c * plane + ab);
+        const unsigned wb1 = share ? wa1 : ld_u32_unaligned(r1 + c * plane + ab);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!ok[h]) continue;
+          const unsigned w0 = h ? wb0 : wa0, w1 = h ? wb1 : wa1;
+          const int sl = h ? s10 : s00, sr = h ? s11 : s01;
+          const float v00 = lut[(w0 >> sl) & 0xffu], v01 = lut[(w0 >> sr) & 0xffu];
+          const float v10 = lut[(w1 >> sl) & 0xffu], v11 = lut[(w1 >> sr) & 0xffu];
+          const float t0 = fmaf(hx[h], v00, lx[h] * v01);
+          const float t1 = fmaf(hx[h], v10, lx[h] * v11);
+          const float v = fmaf(hy, t0, ly * t1) * 255.0f;
+          const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+          const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+          const float rsd = c == 0 ? 1.0f / 0.229f : (c == 1 ? 1.0f / 0.224f : 1.0f / 0.225f);
+          const float n = div_const(div_const(v, 255.0f, 1.0f / 255.0f) - mean, sd, rsd);
+          const int k = 2 * kk + h;
+          o[(k * 3 + c) >> 3][(k * 3 + c) & 7] = (bf16_t)n;
+        }
       }
     }
   }
@@ -154,11 +192,15 @@ __global__ __launch_bounds__(256) void stem_prep16_crop_u8_kernel(const unsigned
 
 int launch_stem_prep16_crop(const FrameSource& src, void* xn16, int F, hipStream_t s) {
   const long long total = (long long)F * XN_ROWS * (XN_ROW / 8);
-  if (src.is_u8) {
+  if (src.is_u8 && src.Wi >= 4) {     // (narrower clips — never a frame — take the generic kernel below: same values)
     const long long tg = (long long)F * XN_ROWS * XN_GROUPS;
     hipLaunchKernelGGL(stem_prep16_crop_u8_kernel, dim3(ceil_div(tg, 256)), dim3(256), 0, s, static_cast<const unsigned char*>(src.frames),
                        src.boxes, reinterpret_cast<bf16_t*>(xn16), tg, src.Hi, src.Wi, src.frames_per_box);
-  } else
+  } else if (src.is_u8)
+    hipLaunchKernelGGL((stem_prep16_crop_kernel<unsigned char>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                       static_cast<const unsigned char*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
+                       src.frames_per_box);
+  else
     hipLaunchKernelGGL((stem_prep16_crop_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s,
                        static_cast<const float*>(src.frames), src.boxes, reinterpret_cast<bf16_t*>(xn16), total, src.Hi, src.Wi,
                        src.frames_per_box);

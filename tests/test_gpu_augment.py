@@ -119,3 +119,38 @@ def test_crop_inside_the_stem_prepass_equals_crop_then_forward(hip, precision, p
         assert torch.equal(res[0][1], res[1][1]), f"gradients differ ({precision}, training={training})"
     with pytest.raises(ValueError):
         clips.reshape(B * T * 3, 224, 224)
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (256, 320), (300, 512), (240, 700), (9, 4), (33, 7)])
+def test_u8_stem_prepass_crop_is_bit_identical_to_the_float_source_kernel(hip, H, W):
+    """Round 6: the uint8 crop pre-pass of the bf16 stem (csrc/stem_bf16.hip stem_prep16_crop_u8_kernel) fetches its source bytes as
+    unaligned dword loads shared by a pixel's two taps and, for down-sampling factors up to 1.5, by a pixel pair — clamped into the
+    source row. Same float operations as the generic kernel on float clips (augment_dev.h): the padded bf16 images must be identical
+    BIT FOR BIT — boxes that touch every edge (clamped loads), tiny boxes (up-sampling: both taps of many pixels in one byte pair),
+    wide clips (factors > 1.5: unshared loads), rows of 4-7 bytes."""
+    g = torch.Generator().manual_seed(5)
+    NF = 7
+    raw = torch.randint(0, 256, (NF, 3, H, W), generator=g, dtype=torch.uint8)
+    boxes = torch.tensor([[0, 0, H, W],                                   # the whole clip: strongest down-sampling this clip allows
+                          [H - min(H, 5), W - min(W, 4), min(H, 5), min(W, 4)],   # bottom-right corner, 4 columns: every load clamped
+                          [0, W - min(W, 9), min(H, 6), min(W, 9)],       # top-right strip
+                          [H // 3, 0, max(1, H // 2), max(1, W // 2)],    # left edge
+                          [1, 1, 1, 1],                                   # one source pixel
+                          [H // 5, W // 7, max(2, H // 2), max(2, int(W * 0.6))],
+                          [0, max(0, W - 224), min(H, 224), min(W, 224)]], dtype=torch.int32)
+    raw_d = raw.to("cuda:0")
+    rawf_d = raw_d.float()
+    boxes_d = boxes.to("cuda:0")
+    nbytes = hip.r3m_stem_xn16_bytes(NF)
+    out_u8 = torch.full((nbytes,), 0x5a, dtype=torch.uint8, device="cuda:0")
+    out_f = torch.full((nbytes,), 0xa5, dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    assert hip.r3m_stem_prep_crop(raw_d.data_ptr(), 1, boxes_d.data_ptr(), 1, H, W, out_u8.data_ptr(), NF, 1, st) == 0, hip.r3m_last_error()
+    assert hip.r3m_stem_prep_crop(rawf_d.data_ptr(), 0, boxes_d.data_ptr(), 1, H, W, out_f.data_ptr(), NF, 1, st) == 0, hip.r3m_last_error()
+    torch.cuda.synchronize()
+    a = out_u8.view(torch.int16).view(NF, 232, 704)
+    b = out_f.view(torch.int16).view(NF, 232, 704)
+    bad = (a != b).nonzero()
+    assert bad.numel() == 0, (bad[:5].tolist(), int((a != b).sum()))
+    # and the image is not trivially empty: the interior rows carry values
+    assert int((a[:, 3:227, 9:681] != 0).sum()) > 0.9 * NF * 224 * 672
