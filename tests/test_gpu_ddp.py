@@ -472,17 +472,20 @@ def test_bench_spawns_its_own_ranks(hip):
     assert plain["n_gpus"] == 1 and "rccl_ranks" not in plain and plain["config"]["collectives"] == "none (single process)"
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo(hip):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_on_one_gpu_over_gloo(hip, world):
     """The N > 1 code of bench.py itself — self-spawned ranks, process group, barriers, all-reduced timing (max over ranks, per-rank
-    min / max), gradient all-reduces inside the step — with TWO ranks on the one GPU of the test box (`--backend gloo --share-gpu`;
-    RCCL refuses two ranks on a device, so the product backend is covered by the world-1 / armed tests above)."""
-    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo" and out["value"] > 0
+    min / max), gradient all-reduces inside the step — with TWO and with EIGHT ranks (the driver's largest launch: rank-indexed code
+    sees ranks >= 2) on the one GPU of the test box (`--backend gloo --share-gpu`; RCCL refuses two ranks on a device, so the product
+    backend is covered by the world-1 / armed tests above)."""
+    out = _run_bench(["--gpus", str(world), "--backend", "gloo", "--share-gpu"])
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["backend"] == "gloo" and out["value"] > 0
     assert out["config"]["collectives"].startswith(f"gloo all_reduce(SUM)/N, {ENC_SLICES[18]:.1f} per step")
-    assert out["config"]["frames_per_gpu"] == 40 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["frames_per_gpu"] == 40 and out["config"]["parallelism"] == f"dp{world}"
+    assert len(out["ms_per_step_by_rank"]) == world and len(out["comm_exposed_ms_by_rank"]) == world
     assert out["ms_per_step_rank_min"] <= out["ms_per_step_rank_max"] == out["ms_per_step"]
-    # whole-job value = both ranks' frames over the slower rank's time
-    assert abs(out["value"] - 2 * 40 * out["steps"] / (out["ms_per_step"] * out["steps"] * 1e-3)) <= 0.01 * out["value"]
+    # whole-job value = every rank's frames over the slowest rank's time
+    assert abs(out["value"] - world * 40 * out["steps"] / (out["ms_per_step"] * out["steps"] * 1e-3)) <= 0.01 * out["value"]
 
 
 # ------------------------------------------------------------------------------------------------------------------------
