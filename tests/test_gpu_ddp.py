@@ -62,7 +62,8 @@ def _worker(rank, world, port, q):
         net = make_network_wrapper(m)
         assert isinstance(net, DistributedR3M)
         frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to("cuda:0")
-        g = _lp_backward(net, frames[rank * 4:(rank + 1) * 4])
+        per = 8 // world
+        g = _lp_backward(net, frames[rank * per:(rank + 1) * per])
         q.put((rank, g.cpu().numpy()))
         dist.barrier()
     except Exception:  # noqa: BLE001
@@ -73,10 +74,12 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_process(hip):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_gradients_equal_single_process(hip, world):
+    """world ranks (2, and 4 so that the slice / hook code sees ranks >= 2) share the test box's GPU over gloo, each with 8 / world
+    frames: every rank ends with the same averaged gradient, equal to the single-process gradient of all 8 frames."""
     from oracle import detgen
     from r3m_amd.parallel import SingleDevice
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -88,7 +91,8 @@ def test_two_rank_gradients_equal_single_process(hip):
         p.join(timeout=120)
     for r, v in res.items():
         assert not isinstance(v, str), f"rank {r}: {v}"
-    np.testing.assert_array_equal(res[0], res[1])          # both ranks hold the same averaged gradient
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0], res[r])      # every rank holds the same averaged gradient
     single = SingleDevice(_build(18))
     frames = torch.from_numpy(detgen.frames("ddp", (8, 3, 224, 224))).to("cuda:0")
     g1 = _lp_backward(single, frames).cpu().numpy()
