@@ -560,11 +560,14 @@ def _check_gneg(res):
     for r, o in res.items():
         assert o["eval_equal"], (r, o["m_glob"], o["m_single"])   # 2 ranks x B/2 reproduce the 1-rank loss scalars bit for bit
         assert o["enc_identical"] and o["head_identical"] and o["finite"], (r, o)
-    assert res[0]["train_metrics"] == res[1]["train_metrics"]       # one global objective: the same numbers on every rank
+    for r in res:
+        assert res[0]["train_metrics"] == res[r]["train_metrics"]   # one global objective: the same numbers on every rank
 
 
-def test_global_negatives_two_ranks_on_one_gpu(hip):
-    _check_gneg(_run_ranks(_gneg_worker, 2, "gloo"))
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_negatives_two_ranks_on_one_gpu(hip, world):
+    """world = 4: one clip per rank — the row offsets of the gathered embeddings and each rank's gradient rows at ranks >= 2."""
+    _check_gneg(_run_ranks(_gneg_worker, world, "gloo"))
 
 
 def test_global_negatives_rccl(hip):
