@@ -278,3 +278,23 @@ def test_pick_slot_keeps_live_forwards():
     assert _pick_slot([True, True], 1, True) == (1, 0)         # all live: the oldest (cursor) goes
     assert _pick_slot([True, True], 1, False) == (-1, 1)
     assert _pick_slot([False, True], 1, True) == (0, 1)
+
+
+def test_profile_tools_keep_kernel_names_of_anonymous_namespaces():
+    """tools/rocpd_stats.py / rocpd_pmc.py shorten rocprofv3 kernel names for the committed tables. Round 6's kernel-row bf16 kernel lives
+    in an anonymous namespace: its demangled name starts with `(anonymous namespace)::`, and cutting at the first `(` left an EMPTY name
+    (a whole evidence set went out with "" rows). Both the demangled and the mangled form must come out as the plain template name."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mod in ("rocpd_stats", "rocpd_pmc"):
+        spec = importlib.util.spec_from_file_location(mod, os.path.join(root, "tools", mod + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        assert m.short("void r3m::(anonymous namespace)::conv3x3_row_bf16_kernel<128, 1>(r3m::GatherGemmParams, int, int)") == \
+            "conv3x3_row_bf16_kernel<128, 1>"
+        assert m.short("void r3m::pw_gemm_kernel<128, 128, 2, 2, 1, false, false, false, false>(r3m::GatherGemmParams)") == \
+            "pw_gemm_kernel<128, 128, 2, 2, 1, false, false, false, false>"
+    spec = importlib.util.spec_from_file_location("rocpd_stats", os.path.join(root, "tools", "rocpd_stats.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.short("_ZN3r3m12_GLOBAL__N_123conv3x3_row_bf16_kernelILi128ELi1EEEvNS_16GatherGemmParamsEii") == "conv3x3_row_bf16_kernel<128, 1>"
